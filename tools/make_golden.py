@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Imports /root/reference/src/python/vimure with the two container-only stub
+modules in tools/oracle_stubs (sktensor, igraph: absent offline, containers
+only -- SURVEY.md App. A) and records, for a set of small seeded problems:
+inputs, the RandomState-seeded initial state, the state after every sub-step
+(gamma, phi, rho, nu) of the first iterations, the ELBO after each of those
+iterations, and the outputs of a complete `fit` (trace, maxL, *_f arrays).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+The reference never travels: only these data vectors are committed.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src/python"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "oracle_stubs"))
+warnings.filterwarnings("ignore")
+
+import pandas as pd  # noqa: E402
+import vimure as vm  # noqa: E402
+from vimure.model import VimureModel  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def synth(L, N, M, eta, seed, density=0.06, mask="ones", outside=0):
+    """Small random multiply-reported network (own generator, not the reference's)."""
+    g = np.random.RandomState(seed)
+    theta = g.gamma(2.0, 0.5, size=(L, M))
+    Y = (g.rand(L, N, N) < density).astype(float)
+    for l in range(L):
+        np.fill_diagonal(Y[l], 0)
+    lam = np.where(Y > 0, 1.0, 0.01)
+    MX = theta[:, None, None, :] * lam[..., None]
+    MM = (MX + eta * MX.transpose(0, 2, 1, 3)) / (1 - eta * eta)
+    first = g.poisson(MM)
+    second = g.poisson(MX.transpose(0, 2, 1, 3) + eta * first)
+    iu = np.triu(np.ones((N, N), bool), 1)
+    X = np.zeros((L, N, N, M), np.int64)
+    X[:, iu, :] = first[:, iu, :]
+    Xt = np.zeros_like(X)
+    Xt[:, iu, :] = second[:, iu, :]
+    X = X + Xt.transpose(0, 2, 1, 3)
+    if mask == "ones":
+        R = np.ones((L, N, N, M), np.int64)
+    elif mask == "random":
+        R = (g.rand(L, N, N, M) < 0.35).astype(np.int64)
+    elif mask == "self":
+        assert M == N
+        R = np.zeros((L, N, N, M), np.int64)
+        reporters = g.rand(N) < 0.7
+        for m in np.nonzero(reporters)[0]:
+            R[:, m, :, m] = 1
+            R[:, :, m, m] = 1
+    X = X * (R > 0)
+    if outside:  # X non-zeros outside R
+        zl, zi, zj, zm = np.nonzero(R == 0)
+        pick = g.choice(len(zl), size=min(outside, len(zl)), replace=False)
+        X[zl[pick], zi[pick], zj[pick], zm[pick]] = g.randint(1, 4, size=len(pick))
+    for l in range(L):
+        for m in range(M):
+            np.fill_diagonal(X[l, :, :, m], 0)
+    return X, R
+
+
+def snap(m, names=("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "nu_rte", "rho")):
+    return {n: np.array(getattr(m, n), dtype=np.float64) for n in names}
+
+
+def run_case(name, X, R, K, mutuality=True, undirected=False, seed=1, n_steps=3, fit_kwargs=None,
+             rho_prior=None, priors=None, save_inputs=True):
+    priors = priors or {}
+    fit_kwargs = dict(fit_kwargs or {})
+    out = {"K": K, "mutuality": int(mutuality), "undirected": int(undirected), "seed": seed}
+    if save_inputs:
+        out["X"] = X.astype(np.uint8)
+        out["R"] = R.astype(np.uint8)
+    assert X.max() <= 255
+    # ---- step-level capture through the reference's private methods
+    m = VimureModel(mutuality=mutuality, undirected=undirected)
+    m._VimureModel__check_fit_params(X=X.copy(), seed=seed, R=R.copy(), K=K, rho_prior=rho_prior, **priors)
+    m._set_rho_prior()
+    m._initialize_priors()
+    m._initialize_old_variables()
+    for k_, v in snap(m, ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "nu_rte", "pr_rho")).items():
+        out["init_" + k_] = v
+    elbos = []
+    for it in range(1, n_steps + 1):
+        for step, names in (("gamma", ("gamma_shp", "gamma_rte")), ("phi", ("phi_shp", "phi_rte")),
+                            ("rho", ("rho",)), ("nu", ("nu_shp",))):
+            if step == "nu" and not m.mutuality:
+                continue
+            m._update_cache(m.X, m.subs_nz, m.data_T_vals)
+            getattr(m, "_update_" + step)(m.subs_nz)
+            for n in names:
+                out[f"it{it}_{n}"] = np.array(getattr(m, n), dtype=np.float64)
+        elbos.append(m._VimureModel__ELBO(m.X, m.data_T, m.subs_nz))
+    out["step_elbo"] = np.array(elbos)
+    # ---- a complete fit
+    m2 = VimureModel(mutuality=mutuality, undirected=undirected)
+    m2.fit(X.copy(), R=R.copy(), K=K, seed=seed, rho_prior=rho_prior, **priors, **fit_kwargs)
+    for n in ("gamma_shp_f", "gamma_rte_f", "phi_shp_f", "phi_rte_f", "nu_shp_f", "nu_rte_f", "rho_f",
+              "G_exp_theta_f", "G_exp_lambda_f", "G_exp_nu_f"):
+        out["fit_" + n] = np.array(getattr(m2, n), dtype=np.float64)
+    out["fit_maxL"] = np.array(m2.maxL)
+    out["fit_final_seed"] = np.array(m2.seed)
+    tr = m2.trace
+    out["fit_trace_realisation"] = tr["realisation"].values.astype(np.int64)
+    out["fit_trace_seed"] = tr["seed"].values.astype(np.int64)
+    out["fit_trace_iter"] = tr["iter"].values.astype(np.int64)
+    out["fit_trace_elbo"] = tr["elbo"].values.astype(np.float64)
+    out["fit_trace_conv"] = tr["reached_convergence"].values.astype(np.int64)
+    for k_, v in fit_kwargs.items():
+        out["fitarg_" + k_] = np.array(v)
+    for k_, v in priors.items():
+        out["prior_" + k_] = np.array(v)
+    if rho_prior is not None:
+        out["rho_prior"] = rho_prior
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: nnzX={np.count_nonzero(X)} nnzR={np.count_nonzero(R)} maxL={m2.maxL!r} "
+          f"iters={tr['iter'].values.tolist()[-3:]} stepELBO={elbos}")
+    return m2
+
+
+def coo_inputs(X, R):
+    xs, rs = np.nonzero(X), np.nonzero(R)
+    return {"X_shape": np.array(X.shape), "X_subs": np.stack(xs).astype(np.int16), "X_vals": X[xs].astype(np.uint8),
+            "R_subs": np.stack(rs).astype(np.int16)}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # A: all-ones dense R, mutuality on
+    X, R = synth(1, 30, 8, 0.5, 11)
+    run_case("A_ones_mut", X, R, 2, seed=1, fit_kwargs=dict(num_realisations=2, max_iter=40))
+    # B: two layers, K=3, random sparse mask with X entries outside R
+    X, R = synth(2, 24, 10, 0.4, 12, mask="random", outside=15)
+    run_case("B_random_mask_K3", X, R, 3, seed=7, fit_kwargs=dict(num_realisations=2, max_iter=30))
+    # C: mutuality off
+    X, R = synth(1, 30, 12, 0.0, 13)
+    run_case("C_ones_nomut", X, R, 2, mutuality=False, seed=3, fit_kwargs=dict(num_realisations=1, max_iter=40))
+    # D: self-reporter mask (Karnataka-like), two layers, M == N
+    X, R = synth(2, 20, 20, 0.3, 14, mask="self", density=0.15)
+    run_case("D_self_mask", X, R, 2, seed=5, fit_kwargs=dict(num_realisations=6, max_iter=21, bias0=0.2))
+    # E: undirected (symmetric X forces mutuality off)
+    X, R = synth(1, 26, 9, 0.0, 15)
+    X = np.maximum(X, X.transpose(0, 2, 1, 3))
+    run_case("E_undirected", X, R, 2, mutuality=True, undirected=True, seed=9,
+             fit_kwargs=dict(num_realisations=1, max_iter=30))
+    # F: informative rho_prior + array-valued lambda priors
+    X, R = synth(1, 22, 10, 0.5, 16)
+    rp = (X.sum(axis=3) > 0).astype(float) * 0.8 + 0.1 * np.random.RandomState(3).rand(1, 22, 22)
+    rp[0, :3, :3] = 0.0
+    run_case("F_rho_prior", X, R, 2, seed=4, rho_prior=rp,
+             priors=dict(alpha_lambda=np.array([[100.0, 10000.0]]), beta_lambda=1e4 * np.ones((1, 2))),
+             fit_kwargs=dict(num_realisations=1, max_iter=20))
+    # G: BASELINE config 1 -- the reference's own StandardSBM generator (SURVEY App. B, C1 plumbing)
+    from vimure.synthetic import StandardSBM, Multitensor
+    g = StandardSBM(N=100, M=10, L=1, K=2, C=2, avg_degree=2, sparsify=False, seed=0)._build_X(flag_self_reporter=True)
+    X, R = g.X.toarray(), g.R.toarray()
+    run_case("G_config1_sbm", X, R, 2, seed=1, n_steps=2)
+    # H: the reference's own known-answer tests (test/test_model.py:117-334): F1 ~ 0.92 (over) / 0.97 (under)
+    from sklearn.metrics import f1_score
+    for tag in ("over", "under"):
+        eta = 0.2
+        gt = Multitensor(N=100, M=100, L=1, C=2, K=2, avg_degree=5, sparsify=True, seed=25, ExpM=None, eta=eta)
+        theta = vm.synthetic.build_custom_theta(gt_network=gt, theta_ratio=0.1, exaggeration_type=tag, seed=25)
+        gt._build_X(mutuality=eta, theta=theta, cutoff_X=False, lambda_diff=0.99, flag_self_reporter=True, seed=25)
+        X, R = gt.X.toarray(), gt.R.toarray()
+        m2 = run_case(f"H_ref_f1_{tag}", X, R, 2, seed=25, n_steps=1, save_inputs=False,
+                      priors=dict(alpha_lambda=np.array([[100.0, 10000.0]]), beta_lambda=1e4 * np.ones((1, 2))),
+                      fit_kwargs=dict(num_realisations=2, max_iter=21))
+        Yrec = (m2.rho_f[0, :, :, 1] >= 0.5).astype(int)
+        Ytrue = gt.Y.toarray()[0]
+        f1 = f1_score(Ytrue.flatten(), Yrec.flatten())
+        path = os.path.join(OUT, f"H_ref_f1_{tag}.npz")
+        d = dict(np.load(path))
+        d.update(coo_inputs(X, R))
+        d["Y_true"] = Ytrue.astype(np.uint8)
+        d["f1"] = np.array(f1)
+        np.savez_compressed(path, **d)
+        print(f"  F1({tag}) = {f1:.4f}")
+    # I: Karnataka village 1, layer 'money' -- data file the reference's own tests read
+    #    (test/__init__.py:18-41, test_model.py:450-481)
+    sys.path.insert(0, "/root/reference/notebooks/python/experiments/")
+    from karnataka import read_village_data
+    df, _, _ = read_village_data("vil1", filter_layer="money", print_details=False,
+                                 data_folder="/root/reference/data/input/india_microfinance/formatted/")
+    df.rename(columns={"Ego": "ego", "Alter": "alter"}, inplace=True)
+    net = vm._io.read_from_edgelist(df, K=2)
+    X, R = net.X.toarray(), net.R.toarray()
+    run_case("I_karnataka_vil1_money", X, R, 2, seed=1, n_steps=1, save_inputs=False,
+             fit_kwargs=dict(num_realisations=1, max_iter=21))
+    path = os.path.join(OUT, "I_karnataka_vil1_money.npz")
+    d = dict(np.load(path))
+    d.update(coo_inputs(X, R))
+    np.savez_compressed(path, **d)
+
+
+if __name__ == "__main__":
+    main()
