@@ -1,0 +1,135 @@
+/*
+ * vimure_hip.h -- C-ABI of libvimure_hip.so, the MI355X (gfx950) CAVI engine for the
+ * VIMuRe latent-network model.
+ *
+ * The reference (latentnetworks/vimure) has no FFI: its hot path is a set of private
+ * methods of `VimureModel` that mutate NumPy arrays held in `self`
+ * (src/python/vimure/model.py).  This header is the seam a maintainer would bind with
+ * ctypes; every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE double, as in the reference;
+ *   - arrays are C-order: X,R [L,N,N,M] (layer, ego, alter, reporter), rho/pr_rho [L,N,N,K],
+ *     gamma_* [L,M], phi_* [L,K];
+ *   - every function returns 0 on success and a negative VMR_E* code on failure;
+ *     vmr_last_error() gives the message (pass NULL for errors of vmr_create);
+ *   - one handle <-> one device <-> one HIP stream; a handle is not re-entrant, distinct
+ *     handles are independent (that is the multi-GPU model: one process per GPU);
+ *   - host pointers are only read/written during the call; the library owns all device memory.
+ */
+#ifndef VIMURE_HIP_H
+#define VIMURE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vmr_ctx* vmr_handle;
+
+enum {
+  VMR_OK = 0,
+  VMR_EINVAL = -1,   /* bad argument / unsupported size (ValueError in the host class) */
+  VMR_EHIP = -2,     /* HIP runtime error (RuntimeError) */
+  VMR_ENAN = -3,     /* ELBO is NaN (model.py:1015-1016 raises ValueError("ELBO is NaN!!!!")) */
+  VMR_ESTATE = -4    /* call order violated (priors/state not set) */
+};
+
+/* sub-steps of one sweep, for vmr_sub_step (model.py:643-656) */
+enum { VMR_STEP_GAMMA = 0, VMR_STEP_PHI = 1, VMR_STEP_RHO = 2, VMR_STEP_NU = 3 };
+
+/* kernel classes for vmr_profile_read */
+enum {
+  VMR_KERNEL_GAMMA_MASK = 0,   /* masked reduction over R: A[l,m,k] = sum_ij R rho           */
+  VMR_KERNEL_GAMMA_COUNTS = 1, /* sweep over X for gamma_shp (and phi_shp when mutuality off) */
+  VMR_KERNEL_PHI = 2,          /* sweep over X for phi_shp (mutuality on)                     */
+  VMR_KERNEL_RHO = 3,          /* sweep over X,R: rho update (+ nu partial, + fused ELBO)     */
+  VMR_KERNEL_ELBO = 4,         /* stand-alone ELBO sweep                                      */
+  VMR_KERNEL_FINALIZE = 5,     /* the small reduce/parameter kernels                          */
+  VMR_KERNEL_COUNT = 6
+};
+
+/*
+ * Dataset handle.  Replaces the data set-up half of `__check_fit_params`
+ * (model.py:134-213): X is kept as dense uint8 counts (rows padded to 16 B), R is packed to
+ * one bit per (l,i,j,m); X^T (model.py:141-161 `data_T`, `data_T_vals`) is never
+ * materialised -- kernels read the mirrored tile instead.
+ *   X  [L,N,N,M] uint8 counts (values <= 255).
+ *   R  [L,N,N,M] uint8 0/1, or NULL = every reporter may report on every tie
+ *      (model.py:206-211 default).
+ *   data_on_device != 0: X and R are device pointers on `device` (e.g. torch tensors).
+ *   mutuality: 0/1 (model.py:60-65; the host class forces 0 for undirected networks).
+ *   eps: the EPS white-noise constant (model.py:215-218), normally 1e-12.
+ * The handle is reusable across realisations and seeds (vmr_set_state restarts it).
+ */
+int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality,
+               const uint8_t* X, const uint8_t* R, int data_on_device, double eps);
+
+void vmr_destroy(vmr_handle h);
+
+const char* vmr_last_error(vmr_handle h);
+
+/* Data statistics the host-side initialisation needs:
+ *   sum_x     = X.vals.sum()  (model.py:174, enters nu_rte at model.py:593-595)
+ *   coverage  [L,N,N] uint8, 1 iff the tie has at least one R entry AND at least one
+ *             non-zero report; ties with 0 get the one-hot rho prior (model.py:508-556).
+ *             May be NULL. */
+int vmr_data_stats(vmr_handle h, double* sum_x, uint8_t* coverage);
+
+/* Hyper-parameters, already broadcast to full arrays by the host (model.py:238-317):
+ * alpha/beta_theta [L,M], alpha/beta_lambda [L,K], eta prior scalars. */
+int vmr_set_priors(vmr_handle h, const double* alpha_theta, const double* beta_theta,
+                   const double* alpha_lambda, const double* beta_lambda,
+                   double alpha_eta, double beta_eta);
+
+/* Start of a realisation: `_initialize_priors` + `_initialize_old_variables`
+ * (model.py:561-617).  The host draws the values from RandomState (model.py:470-482,
+ * 570-592) so fixed-seed fits match the reference; the library sets rho <- pr_rho and
+ * logpr_rho <- log(pr_rho + eps) (model.py:559, 602).
+ * pr_rho_on_device != 0: pr_rho is a device pointer. */
+int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte,
+                  const double* phi_shp, const double* phi_rte, double nu_shp, double nu_rte,
+                  const double* pr_rho, int pr_rho_on_device);
+
+/* n_iters full sweeps of `_update_CAVI` (model.py:623-660): gamma -> phi -> rho -> nu, each
+ * with the cache refresh of model.py:662-696 fused in.  Asynchronous on the handle's stream
+ * unless elbo_out != NULL, in which case the ELBO (`__ELBO`, model.py:948-1019) is reduced
+ * inside the last sweep's rho pass and returned (this synchronises). */
+int vmr_step(vmr_handle h, int n_iters, double* elbo_out);
+
+/* Stand-alone ELBO of the current state (model.py:948-1019 incl. the stale G_exp_nu of
+ * model.py:970).  Synchronises.  Returns VMR_ENAN when the value is NaN. */
+int vmr_elbo(vmr_handle h, double* out);
+
+/* One update of a sweep (test hook for step-level parity with model.py:643-656). */
+int vmr_sub_step(vmr_handle h, int which);
+
+/* Copy the posteriors to the host: what `_update_optimal_parameters` snapshots
+ * (model.py:925-942).  Any pointer may be NULL.  Synchronises. */
+int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* phi_shp,
+                  double* phi_rte, double* nu_shp, double* nu_rte, double* rho);
+
+/* exp(E[log .]) of theta [L,M], lambda [L,K], nu as the cache holds them
+ * (model.py:676-684): G_exp_theta, G_exp_lambda, G_exp_nu.  Any pointer may be NULL. */
+int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu);
+
+/* Wait for all work queued on the handle's stream. */
+int vmr_sync(vmr_handle h);
+
+/* Per-kernel-class timing with HIP events on the handle's stream (for bench.py's roofline
+ * line).  enable=1 starts recording and clears totals. vmr_profile_read synchronises. */
+int vmr_profile(vmr_handle h, int enable);
+int vmr_profile_read(vmr_handle h, int kernel_class, double* total_ms, int64_t* launches);
+
+/* Algorithmic bytes one launch of a kernel class moves under the canonical dense encoding
+ * (X 1 B/elt, R 1 bit/elt, rho/logpr_rho 8 B), see DESIGN.md. */
+int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes);
+
+/* Library/version string. */
+const char* vmr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIMURE_HIP_H */

@@ -1,0 +1,169 @@
+"""Object wrapper over the C-ABI: one `CaviEngine` = one dataset on one MI355X.
+
+The engine owns the device copies of X (uint8) and R (bit mask) and the variational
+state; the host (`vimure_amd.model.VimureModel`) only draws the RandomState-seeded
+initial values and applies the ELBO stop rule.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class CaviEngine:
+    def __init__(self, X, R=None, K=2, mutuality=True, eps=1e-12, device=None):
+        self._h = C.c_void_p()
+        self.lib = _lib.load()
+        on_dev = _is_torch(X)
+        if on_dev:
+            if not X.is_cuda or X.dtype.__str__() != "torch.uint8" or not X.is_contiguous():
+                raise ValueError("device X must be a contiguous torch.uint8 tensor on the GPU")
+            if R is not None and (not _is_torch(R) or not R.is_cuda or R.dtype.__str__() != "torch.uint8"
+                                  or not R.is_contiguous() or tuple(R.shape) != tuple(X.shape)):
+                raise ValueError("device R must be a contiguous torch.uint8 GPU tensor shaped like X")
+            if device is None:
+                device = X.device.index or 0
+            import torch
+            torch.cuda.synchronize(X.device)
+            xp, rp = X.data_ptr(), (R.data_ptr() if R is not None else None)
+            shape = tuple(X.shape)
+        else:
+            X = np.ascontiguousarray(X, dtype=np.uint8)
+            if R is not None:
+                R = np.ascontiguousarray(R, dtype=np.uint8)
+                if R.shape != X.shape:
+                    raise ValueError("Dimensions of reporter mask (R) do not match L x N x N x M")
+            xp, rp = X.ctypes.data, (R.ctypes.data if R is not None else None)
+            shape = X.shape
+            if device is None:
+                device = 0
+        if len(shape) != 4 or shape[1] != shape[2]:
+            raise ValueError("X must have shape (L, N, N, M)")
+        self.L, self.N, _, self.M = (int(s) for s in shape)
+        self.K, self.mutuality, self.device = int(K), bool(mutuality), int(device)
+        rc = self.lib.vmr_create(C.byref(self._h), self.device, self.L, self.N, self.M, self.K, int(self.mutuality),
+                                 xp, rp, int(on_dev), float(eps))
+        if rc != 0:
+            msg = self.lib.vmr_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise (ValueError if rc == _lib.VMR_EINVAL else EngineError)(msg)
+        self._keep = (X, R)
+
+    # -- helpers
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.vmr_last_error(self._h).decode()
+        if rc in (_lib.VMR_EINVAL, _lib.VMR_ENAN):
+            raise ValueError(msg)
+        raise EngineError(msg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.vmr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data
+    def data_stats(self, coverage=True):
+        s = C.c_double()
+        cov = np.empty((self.L, self.N, self.N), np.uint8) if coverage else None
+        self._check(self.lib.vmr_data_stats(self._h, C.byref(s), cov.ctypes.data if coverage else None))
+        return s.value, cov
+
+    # -- parameters
+    def set_priors(self, alpha_theta, beta_theta, alpha_lambda, beta_lambda, alpha_eta, beta_eta):
+        at = _f64(np.broadcast_to(alpha_theta, (self.L, self.M)))
+        bt = _f64(np.broadcast_to(beta_theta, (self.L, self.M)))
+        al = _f64(np.broadcast_to(alpha_lambda, (self.L, self.K)))
+        bl = _f64(np.broadcast_to(beta_lambda, (self.L, self.K)))
+        self._check(self.lib.vmr_set_priors(self._h, at.ctypes.data, bt.ctypes.data, al.ctypes.data, bl.ctypes.data,
+                                            float(alpha_eta), float(beta_eta)))
+
+    def set_state(self, gamma_shp, gamma_rte, phi_shp, phi_rte, nu_shp, nu_rte, pr_rho):
+        gs, gr, ps, pr = _f64(gamma_shp), _f64(gamma_rte), _f64(phi_shp), _f64(phi_rte)
+        assert gs.shape == (self.L, self.M) and gr.shape == gs.shape
+        assert ps.shape == (self.L, self.K) and pr.shape == ps.shape
+        if _is_torch(pr_rho):
+            assert pr_rho.is_cuda and pr_rho.is_contiguous() and tuple(pr_rho.shape) == (self.L, self.N, self.N, self.K)
+            import torch
+            assert pr_rho.dtype == torch.float64
+            torch.cuda.synchronize(pr_rho.device)
+            pp, dev = pr_rho.data_ptr(), 1
+        else:
+            pr_rho = _f64(pr_rho)
+            assert pr_rho.shape == (self.L, self.N, self.N, self.K)
+            pp, dev = pr_rho.ctypes.data, 0
+        self._check(self.lib.vmr_set_state(self._h, gs.ctypes.data, gr.ctypes.data, ps.ctypes.data, pr.ctypes.data,
+                                           float(nu_shp), float(nu_rte), pp, dev))
+
+    # -- CAVI
+    def step(self, n_iters=1, want_elbo=False):
+        if want_elbo:
+            e = C.c_double()
+            self._check(self.lib.vmr_step(self._h, int(n_iters), C.byref(e)))
+            return e.value
+        self._check(self.lib.vmr_step(self._h, int(n_iters), None))
+        return None
+
+    def elbo(self):
+        e = C.c_double()
+        self._check(self.lib.vmr_elbo(self._h, C.byref(e)))
+        return e.value
+
+    def sub_step(self, which):
+        self._check(self.lib.vmr_sub_step(self._h, int(which)))
+
+    def sync(self):
+        self._check(self.lib.vmr_sync(self._h))
+
+    def get_state(self, rho=True):
+        out = {
+            "gamma_shp": np.empty((self.L, self.M)), "gamma_rte": np.empty((self.L, self.M)),
+            "phi_shp": np.empty((self.L, self.K)), "phi_rte": np.empty((self.L, self.K)),
+        }
+        ns, nr = C.c_double(), C.c_double()
+        r = np.empty((self.L, self.N, self.N, self.K)) if rho else None
+        self._check(self.lib.vmr_get_state(
+            self._h, out["gamma_shp"].ctypes.data, out["gamma_rte"].ctypes.data, out["phi_shp"].ctypes.data,
+            out["phi_rte"].ctypes.data, C.addressof(ns), C.addressof(nr), r.ctypes.data if rho else None))
+        out["nu_shp"], out["nu_rte"] = ns.value, nr.value
+        if rho:
+            out["rho"] = r
+        return out
+
+    def get_geometric(self):
+        gt, gl, gn = np.empty((self.L, self.M)), np.empty((self.L, self.K)), C.c_double()
+        self._check(self.lib.vmr_get_geometric(self._h, gt.ctypes.data, gl.ctypes.data, C.addressof(gn)))
+        return gt, gl, gn.value
+
+    # -- measurement
+    def profile(self, enable=True):
+        self._check(self.lib.vmr_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        out = {}
+        for i, name in enumerate(_lib.KERNEL_NAMES):
+            ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+            self._check(self.lib.vmr_profile_read(self._h, i, C.byref(ms), C.byref(n)))
+            self._check(self.lib.vmr_kernel_bytes(self._h, i, C.byref(b)))
+            out[name] = {"ms": ms.value, "launches": n.value, "bytes_per_launch": b.value}
+        return out
