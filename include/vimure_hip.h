@@ -110,9 +110,11 @@ int vmr_sub_step(vmr_handle h, int which);
 int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* phi_shp,
                   double* phi_rte, double* nu_shp, double* nu_rte, double* rho);
 
-/* exp(E[log .]) of theta [L,M], lambda [L,K], nu as the cache holds them
- * (model.py:676-684): G_exp_theta, G_exp_lambda, G_exp_nu.  Any pointer may be NULL. */
-int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu);
+/* exp(E[log .]) of theta [L,M], lambda [L,K], nu from the current shape/rate parameters
+ * (model.py:676-684), plus g_nu_cache = the G_exp_nu the last cache refresh held, i.e. the
+ * value computed BEFORE the last nu update -- what `model.G_exp_nu` reads after `fit` and what
+ * the ELBO uses (model.py:684 vs :822, :970).  Any pointer may be NULL. */
+int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu, double* g_nu_cache);
 
 /* Wait for all work queued on the handle's stream. */
 int vmr_sync(vmr_handle h);

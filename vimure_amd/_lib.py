@@ -30,7 +30,7 @@ SIGNATURES = {
     "vmr_elbo": (C.c_int, [C.c_void_p, _dp]),
     "vmr_sub_step": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
-    "vmr_get_geometric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vmr_get_geometric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vmr_sync": (C.c_int, [C.c_void_p]),
     "vmr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_profile_read": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
@@ -50,6 +50,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP engine has not been built. Run `python -m vimure_amd.build` "
             "(needs hipcc, --offload-arch=gfx950). vimure_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process cannot both own the
+    # GPU.  Import torch first (when present) so that this library binds to the runtime torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

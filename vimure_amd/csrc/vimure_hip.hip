@@ -1198,7 +1198,7 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
   return VMR_OK;
 }
 
-int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu) {
+int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu, double* g_nu_cache) {
   if (!h) return VMR_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1208,6 +1208,7 @@ int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g
   if (g_theta && (rc = download_lm(h, o.G_th, g_theta))) return rc;
   if (g_lambda) HIPCHK(h, hipMemcpy(g_lambda, h->par + o.G_la, (size_t)g.L * g.K * 8, hipMemcpyDeviceToHost));
   if (g_nu) HIPCHK(h, hipMemcpy(g_nu, h->par + o.sc + SC_G_NU, 8, hipMemcpyDeviceToHost));
+  if (g_nu_cache) HIPCHK(h, hipMemcpy(g_nu_cache, h->par + o.sc + SC_G_NU_STALE, 8, hipMemcpyDeviceToHost));
   return VMR_OK;
 }
 

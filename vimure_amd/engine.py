@@ -151,9 +151,10 @@ class CaviEngine:
         return out
 
     def get_geometric(self):
-        gt, gl, gn = np.empty((self.L, self.M)), np.empty((self.L, self.K)), C.c_double()
-        self._check(self.lib.vmr_get_geometric(self._h, gt.ctypes.data, gl.ctypes.data, C.addressof(gn)))
-        return gt, gl, gn.value
+        gt, gl, gn, gc = np.empty((self.L, self.M)), np.empty((self.L, self.K)), C.c_double(), C.c_double()
+        self._check(self.lib.vmr_get_geometric(self._h, gt.ctypes.data, gl.ctypes.data, C.addressof(gn),
+                                               C.addressof(gc)))
+        return gt, gl, gn.value, gc.value
 
     # -- measurement
     def profile(self, enable=True):

@@ -1,0 +1,57 @@
+"""Minimal COO container with the attribute surface the reference uses from
+`sktensor.sptensor` (subs, vals, shape, toarray) -- reference utils.py:115-132, 220-248.
+The engine itself works on dense uint8 X and a bit-packed R."""
+import numpy as np
+
+
+class SparseTensor:
+    def __init__(self, subs, vals, shape=None, dtype=None):
+        if not isinstance(subs, tuple):
+            raise ValueError("Subscripts must be a tuple of array-likes")
+        self.subs = tuple(np.asarray(s, dtype=np.int64) for s in subs)
+        self.vals = np.asarray(vals, dtype=dtype)
+        if len(self.subs) and len(self.subs[0]) != len(self.vals):
+            raise ValueError("Subscripts and values must be of equal length")
+        if shape is None:
+            shape = tuple(int(s.max()) + 1 for s in self.subs)
+        self.shape = tuple(int(s) for s in shape)
+        self.ndim = len(self.shape)
+        self.dtype = self.vals.dtype
+
+    def __len__(self):
+        return len(self.vals)
+
+    def toarray(self, dtype=None):
+        out = np.zeros(self.shape, dtype=dtype or self.dtype)
+        if len(self.vals):
+            out[self.subs] = self.vals
+        return out
+
+    @classmethod
+    def fromarray(cls, A):
+        A = np.asarray(A)
+        subs = np.nonzero(A)
+        return cls(subs, A[subs], shape=A.shape, dtype=A.dtype)
+
+
+def is_sparse_like(X):
+    """Duck-typed COO tensor (ours, or a real sktensor.sptensor if the user has one)."""
+    return hasattr(X, "subs") and hasattr(X, "vals") and hasattr(X, "shape")
+
+
+def to_dense_u8(X, what="X"):
+    """ndarray / COO container -> C-contiguous uint8 [L,N,N,M]; counts must lie in [0,255]."""
+    if is_sparse_like(X):
+        vals = np.asarray(X.vals)
+        if len(vals) and (vals.min() < 0 or vals.max() > 255):
+            raise ValueError(f"{what} entries must be integers in [0, 255] for the uint8 device layout")
+        out = np.zeros(tuple(int(s) for s in X.shape), np.uint8)
+        if len(vals):
+            out[tuple(np.asarray(s, dtype=np.int64) for s in X.subs)] = vals.astype(np.uint8)
+        return out
+    A = np.asarray(X)
+    if A.dtype != np.uint8:
+        if A.size and (A.min() < 0 or A.max() > 255):
+            raise ValueError(f"{what} entries must be integers in [0, 255] for the uint8 device layout")
+        A = A.astype(np.int64).astype(np.uint8) if A.dtype.kind == "f" else A.astype(np.uint8)
+    return np.ascontiguousarray(A)
