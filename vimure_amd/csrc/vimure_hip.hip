@@ -20,8 +20,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
+#include <utility>
 
 #include "vimure_hip.h"
 
@@ -45,8 +47,13 @@ struct Geo {
   long long P;  // tile pairs per layer
   int Gl;       // workgroups per layer for tile-pair kernels
   int Gm;       // workgroups per layer for the mask kernel
+  int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
+  int dbg;      // timing experiments only (env VMR_DEBUG): 1 = skip per-report math, 2 = skip the scan
   double eps;
 };
+
+#define NSLOT 8   // accumulation slots per layer for cross-workgroup sums (global f64 atomics)
+#define YT 2      // weight table covers mirror counts 0..YT; larger counts use a fast reciprocal
 
 struct vmr_ctx {
   Geo g;
@@ -63,9 +70,12 @@ struct vmr_ctx {
   double* par = nullptr;       // parameter block, see P_* offsets
   size_t par_doubles = 0;
   // partials
-  double *partS1 = nullptr, *partA = nullptr, *partP = nullptr, *partR = nullptr, *Atot = nullptr;
+  double *slotS1 = nullptr, *slotA = nullptr, *slotP = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
   double* elbo_dev = nullptr;  // [0] elbo
   bool have_priors = false, have_state = false;
+  bool slotR_dirty = false;
+  int ncu = 256;
+  std::vector<std::pair<const void*, int>> occ;   // kernel -> resident workgroups per CU   // a rho sub-step left an unconsumed nu partial in slotR
   // profiling
   bool prof = false;
   struct Ev { int cls; hipEvent_t a, b; };
@@ -160,54 +170,11 @@ __device__ __forceinline__ unsigned nz_mask16(uint4 v) {
   return nz_mask4(v.x) | (nz_mask4(v.y) << 4) | (nz_mask4(v.z) << 8) | (nz_mask4(v.w) << 12);
 }
 
-// Visit the non-zero counts of the chunks {s, s+S, ...} of one LDS row: f(m, x).
-// Every lane advances through its own non-zeros; zero chunks cost one 16-B LDS read.
-template <class F>
-__device__ __forceinline__ void scan_row(const unsigned char* row, int s, int S, int nchunk, F&& f) {
-  int c = s, cc = 0;
-  unsigned nzm = 0;
-  for (;;) {
-    while (nzm == 0 && c < nchunk) {
-      uint4 v = *reinterpret_cast<const uint4*>(row + c * 16);
-      nzm = nz_mask16(v);
-      cc = c;
-      c += S;
-    }
-    if (nzm == 0) break;
-    int i = __builtin_ctz(nzm);
-    nzm &= nzm - 1;
-    int m = cc * 16 + i;
-    f(m, (unsigned)row[m]);
-  }
-}
-
 // weight of the theta*lambda part of a report (model.py:685-693): z1 / (z1 + z2), 0-safe
 __device__ __forceinline__ double w1_of(double z1, double z2) {
   double den = z1 + z2;
   den = (den == 0.0) ? 1.0 : den;
   return z1 / den;
-}
-
-struct TileCtx {
-  int N, b, lb, bb;
-  int I0, J0;
-  bool diag;
-};
-
-// tie slot tau of the pair (I,J) -> (i,j); false when outside the network
-__device__ __forceinline__ bool tie_coords(const TileCtx& t, int tau, int& i, int& j) {
-  bool second = tau >= t.bb;
-  int u = second ? tau - t.bb : tau;
-  int p = u >> t.lb, q = u & (t.b - 1);
-  i = (second ? t.J0 : t.I0) + p;
-  j = (second ? t.I0 : t.J0) + q;
-  return i < t.N && j < t.N;
-}
-__device__ __forceinline__ int mirror_slot(const TileCtx& t, int tau) {
-  bool second = tau >= t.bb;
-  int u = second ? tau - t.bb : tau;
-  int m = ((u & (t.b - 1)) << t.lb) | (u >> t.lb);
-  return t.diag ? m : (second ? m : t.bb + m);
 }
 
 // decode pair index p -> (I,J), I <= J, row-major over the upper triangle of an nb x nb grid
@@ -223,21 +190,171 @@ __device__ __forceinline__ void pair_decode(long long p, int nb, int& I, int& J)
   J = (int)(i + (p - off(i)));
 }
 
-// cooperative load of the tile pair's X rows into LDS (zero-fill outside the network)
-__device__ __forceinline__ void load_tile(const uint8_t* __restrict__ Xl, unsigned char* xt, const Geo& g,
-                                          const TileCtx& t, int nt_cur) {
-  const int total = nt_cur * g.nchunk;
-  int q = threadIdx.x;
-  int tau = q / g.nchunk, c = q - tau * g.nchunk;
-  const int dt = TPB / g.nchunk, dc = TPB - dt * g.nchunk;
-  for (; q < total; q += TPB) {
-    int i, j;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tie_coords(t, tau, i, j))
-      v = *reinterpret_cast<const uint4*>(Xl + ((size_t)i * g.N + j) * g.Mp + c * 16);
-    *reinterpret_cast<uint4*>(xt + tau * g.stride + c * 16) = v;
-    tau += dt; c += dc;
-    if (c >= g.nchunk) { c -= g.nchunk; ++tau; }
+// Register-staged stream of tile pairs.  The 16-B chunks a thread stages are the same slots of
+// every tile pair, so their byte offsets from the two sub-tile bases (I,J) / (J,I) and their LDS
+// offsets are computed once; fetch() is one saddr+voffset global_load_dwordx4 per slot and the
+// loads stay in flight while the previous tile pair is processed.  Reads never need a bounds
+// check: X is allocated with b*N+b rows of slack, and rows outside the network are never used.
+template <int PF>
+struct TileStream {
+  uint4 buf[PF];
+  unsigned goff[PF];
+  unsigned loff[PF];
+  unsigned valid, second;   // bit u: slot exists / belongs to the mirrored sub-tile
+  __device__ __forceinline__ void init(const Geo& g) {
+    valid = 0; second = 0;
+    const int bb = g.b * g.b;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int q = threadIdx.x + u * TPB;
+      int tau = q / g.nchunk, c = q - tau * g.nchunk;
+      bool ok = tau < g.nt, sec = tau >= bb;
+      int v = sec ? tau - bb : tau;
+      int p = v >> g.lb, qq = v & (g.b - 1);
+      goff[u] = ok ? (unsigned)((p * g.N + qq) * g.Mp + c * 16) : 0u;
+      loff[u] = ok ? (unsigned)(tau * g.stride + c * 16) : 0u;
+      valid |= (ok ? 1u : 0u) << u;
+      second |= (sec ? 1u : 0u) << u;
+    }
+  }
+  __device__ __forceinline__ void fetch(const uint8_t* __restrict__ Xl, const Geo& g, int I0, int J0) {
+    const uint8_t* baseA = Xl + ((size_t)I0 * g.N + J0) * g.Mp;
+    const uint8_t* baseB = Xl + ((size_t)J0 * g.N + I0) * g.Mp;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      // (assign every slot unconditionally: a conditionally written array would live in scratch)
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((valid >> u) & 1u) {
+        const uint8_t* base = ((second >> u) & 1u) ? baseB : baseA;
+        v = *reinterpret_cast<const uint4*>(base + goff[u]);
+      }
+      buf[u] = v;
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* xt) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if ((valid >> u) & 1u) *reinterpret_cast<uint4*>(xt + loff[u]) = buf[u];
+  }
+};
+
+// 1/d to ~1 ulp: v_rcp_f64 + two Newton steps (the IEEE divide costs about twice as much)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+// Weight table (cache refresh of model.py:685-693 hoisted out of the per-report path):
+//   wt[(y*Mp + m)*K + k] = z1/(z1 + G_nu*y), z1 = G_theta[m] G_lambda[k], for mirror counts y = 0..YT
+// (y = 0 gives 1, or 0 when z1 underflows -- the reference's den==0 -> 1 rule).
+template <int K>
+__device__ __forceinline__ void build_wt(double* wt, const double* Gth, const double (&Gla)[K], double gnu, int Mp) {
+  for (int q = threadIdx.x; q < (YT + 1) * Mp; q += TPB) {
+    int y = q / Mp, m = q - y * Mp;
+#pragma unroll
+    for (int k = 0; k < K; ++k) wt[(size_t)q * K + k] = w1_of(Gth[m] * Gla[k], gnu * (double)y);
+  }
+}
+template <int K>
+__device__ __forceinline__ void weights(double (&w)[K], const double* wt, const double* Gth, const double (&Gla)[K],
+                                        double gnu, int Mp, int m, unsigned y) {
+  if (y <= YT) {
+    const double* p = wt + ((size_t)y * Mp + m) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = p[k];
+  } else {   // y > 0 here, so z1 + z2 > 0
+    const double z2 = gnu * (double)y, gt = Gth[m];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { double z1 = gt * Gla[k]; w[k] = z1 * fast_rcp(z1 + z2); }
+  }
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), lane));
+}
+
+#define HEAVY_ROW 12   // more non-zeros than this in a lane's share of a row -> the whole wave helps
+
+// Visit the non-zero counts of one tie row in LDS.  Lane (tau, s) owns the 16-B chunks {s, s+S, ..}.
+//   phase 1 (no divergence): non-zero-byte masks of up to 12 chunks, 16 bits each, in three words;
+//   light shares: the lane walks its own set bits -- f(m, x, own, acc);
+//   heavy shares (a true tie is reported by most reporters: ~100 non-zeros in one row while the
+//   typical row has 2-5): the share's masks and context are broadcast with v_readlane and all 64
+//   lanes take one bit position each -- f(m, x, bc(h), tmp) -- then fin(h, tmp) hands tmp back.
+// Must be called by every lane of the wave (act = false for lanes without a tie).
+template <class Ctx, class Acc, class F, class BC, class FIN>
+__device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, int tau, int s, bool act, const Ctx& own,
+                                         Acc& acc, F&& f, BC&& bc, FIN&& fin) {
+  const int S = g.S, nchunk = g.nchunk;
+  const unsigned char* row = xt + tau * g.stride;
+  if ((nchunk + S - 1) / S > 12) {   // huge M (b = 1): plain chunk-by-chunk walk
+    if (!act) return;
+    for (int c = s; c < nchunk; c += S) {
+      unsigned nzm = nz_mask16(*reinterpret_cast<const uint4*>(row + c * 16));
+      while (nzm) {
+        int i = __builtin_ctz(nzm);
+        nzm &= nzm - 1;
+        f(c * 16 + i, (unsigned)row[c * 16 + i], own, acc);
+      }
+    }
+    return;
+  }
+  uint64_t mk[3] = {0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if ((w * 4 + u) * S < nchunk) {   // wave-uniform
+          int c = s + (w * 4 + u) * S;
+          int cl = c < nchunk ? c : nchunk - 1;
+          uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
+          unsigned m16 = c < nchunk ? nz_mask16(v) : 0u;
+          mk[w] |= (uint64_t)m16 << (16 * u);
+        }
+      }
+    }
+  }
+  const int cnt = __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]);
+  const bool heavy = cnt > HEAVY_ROW;
+  if (!heavy) {
+    uint64_t cur = mk[0];
+    int w = 0;
+    for (;;) {
+      while (cur == 0 && w < 2) { ++w; cur = (w == 1) ? mk[1] : mk[2]; }
+      if (cur == 0) break;
+      int bit = __builtin_ctzll(cur);
+      cur &= cur - 1;
+      int m = (s + (w * 4 + (bit >> 4)) * S) * 16 + (bit & 15);
+      f(m, (unsigned)row[m], own, acc);
+    }
+  }
+  uint64_t hm = __ballot(heavy);
+  const int lane = threadIdx.x & 63;
+  while (hm) {
+    const int h = __builtin_ctzll(hm);
+    hm &= hm - 1;
+    const Ctx ch = bc(h);
+    const int tau_h = __builtin_amdgcn_readlane(tau, h), s_h = __builtin_amdgcn_readlane(s, h);
+    const uint64_t m0 = readlane64(mk[0], h), m1 = readlane64(mk[1], h), m2 = readlane64(mk[2], h);
+    const unsigned char* rowh = xt + tau_h * g.stride;
+    Acc tmp;
+    tmp.zero();
+    for (int w = 0; w < 3; ++w) {
+      const uint64_t mw = (w == 0) ? m0 : (w == 1) ? m1 : m2;
+      if ((mw >> lane) & 1ull) {
+        int m = (s_h + (w * 4 + (lane >> 4)) * S) * 16 + (lane & 15);
+        f(m, (unsigned)rowh[m], ch, tmp);
+      }
+    }
+    fin(h, tmp);
   }
 }
 
@@ -332,11 +449,16 @@ __global__ void k_derive_all(double* par, Geo g) {
 // gamma, mask half:  A[l,m,k] = sum_{i,j} R[l,i,j,m] rho[l,i,j,k]
 // (gives gamma_rte = beta + sum_k E[lambda_k] A  -- model.py:704-718 -- and, with the new
 //  E[theta], phi_rte = beta + sum_m E[theta_m] A -- model.py:742-749 -- from ONE pass over R)
+// Output: slotA[l][slot][m][k] accumulated with global f64 atomics (zeroed by k_fin_gamma).
 // ------------------------------------------------------------------------------------------
-template <int K>
+// A wave takes 64 consecutive ties per trip, lane <-> tie for the (coalesced, prefetched) loads of
+// the R-row words and rho.  Rows whose words are all ones only feed a per-lane sum (one v_add_f64
+// per k and 64 ties); every other row is broadcast with v_readlane and added under EXEC = its bits
+// (lane <-> reporter).
+template <int K, int NC>
 __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__ Rb, const double* __restrict__ rho,
-                                                    double* __restrict__ partA, Geo g) {
-  __shared__ double sacc[256 * K];
+                                                    double* __restrict__ slotA, Geo g) {
+  __shared__ double sacc[NC * 64 * K];
   const int l = blockIdx.x / g.Gm, gb = blockIdx.x - l * g.Gm;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -346,42 +468,85 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
   const uint64_t* Rl = Rb + (size_t)l * T * g.W;
   const double* rl = rho + (size_t)l * T * K;
   const int Wp = g.W * 64;
-  for (int cg = 0; cg < g.W; cg += 4) {
-    double acc[4][K];
+  for (int cg = 0; cg < g.W; cg += NC) {
+    const int nc = min(NC, g.W - cg);   // == NC except in the last group of a wide mask
+    double acc[NC][K], accF[K];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int k = 0; k < K; ++k) {
+      accF[k] = 0.0;
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[c][k] = 0.0;
-    const int nc = min(4, g.W - cg);
-#pragma unroll 2
-    for (long long t = t0; t < t1; ++t) {
-      const uint64_t* rw = Rl + t * g.W + cg;
-      const double* rp = rl + t * K;
+      for (int c = 0; c < NC; ++c) acc[c][k] = 0.0;
+    }
+    uint64_t fm[NC];   // the word of an every-reporter row (last word: only bits m < M)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int rem = g.M - (cg + c) * 64;
+      fm[c] = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
+    }
+    uint64_t wq[NC];
+    double rq[K];
+    auto fetch = [&](long long tb) {
+      long long t = tb + lane;
+      bool ok = t < t1;
+      long long tc = ok ? t : t1 - 1;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) wq[c] = (ok && c < nc) ? Rl[tc * g.W + cg + c] : 0ull;
+#pragma unroll
+      for (int k = 0; k < K; ++k) rq[k] = ok ? rl[tc * K + k] : 0.0;
+    };
+    if (t0 < t1) fetch(t0);
+    for (long long tb = t0; tb < t1; tb += 64) {
+      uint64_t w[NC];
       double r[K];
 #pragma unroll
-      for (int k = 0; k < K; ++k) r[k] = rp[k];
+      for (int c = 0; c < NC; ++c) w[c] = wq[c];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c < nc) {
-          uint64_t w = rw[c];
-          if (__builtin_amdgcn_inverse_ballot_w64(w)) {
+      for (int k = 0; k < K; ++k) r[k] = rq[k];
+      if (tb + 64 < t1) fetch(tb + 64);   // in flight during this batch
+      bool full = tb + lane < t1, any = false;
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[c][k] += r[k];
+      for (int c = 0; c < NC; ++c) {
+        if (c < nc) { full = full && (w[c] == fm[c]); any = any || (w[c] != 0ull); }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) accF[k] += full ? r[k] : 0.0;
+      uint64_t todo = __ballot(any && !full);
+      while (todo) {
+        int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        double ri[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) ri[k] = readlane_f64(r[k], i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c < nc) {
+            uint64_t wi = readlane64(w[c], i);
+            if (__builtin_amdgcn_inverse_ballot_w64(wi)) {
+#pragma unroll
+              for (int k = 0; k < K; ++k) acc[c][k] += ri[k];
+            }
           }
         }
       }
     }
-    // combine the 4 waves and emit this block's partial for reporters [64 cg, 64 cg + 256)
-    for (int q = threadIdx.x; q < 256 * K; q += TPB) sacc[q] = 0.0;
+    // all-ones rows: every reporter of the group gets the same sum
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double u = wave_sum(accF[k]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (c < nc && (cg + c) * 64 + lane < g.M) acc[c][k] += u;
+    }
+    // combine the 4 waves in LDS, then one global atomic per (m,k) and workgroup
+    for (int q = threadIdx.x; q < NC * 64 * K; q += TPB) sacc[q] = 0.0;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (c < nc) atomicAdd(&sacc[(c * 64 + lane) * K + k], acc[c][k]);
+      for (int k = 0; k < K; ++k) atomicAdd(&sacc[(c * 64 + lane) * K + k], acc[c][k]);
     __syncthreads();
-    double* out = partA + ((size_t)blockIdx.x * Wp + cg * 64) * K;
-    for (int q = threadIdx.x; q < nc * 64 * K; q += TPB) out[q] = sacc[q];
+    double* out = slotA + (((size_t)l * NSLOT + (gb % NSLOT)) * Wp + cg * 64) * K;
+    for (int q = threadIdx.x; q < nc * 64 * K; q += TPB) atomicAdd(&out[q], sacc[q]);
     __syncthreads();
   }
 }
@@ -390,81 +555,133 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 // gamma, counts half (model.py:698-703, 832-859):
 //   S1[l,m] = sum_{ij: x>0} x * sum_k rho_k w1_k        (gamma_shp - alpha)
 //   mutuality off also P[l,k] = sum x rho_k               (phi_shp - alpha, model.py:861-887)
+// Outputs accumulate into slots (slotS1[l][slot][m], slotP[l][slot][k]).
 // ------------------------------------------------------------------------------------------
 struct CountArgs {
   const uint8_t* X; const double* rho; const double* par;
-  double* partS1; double* partP;
+  double* slotS1; double* slotP;
+  int Gl;   // workgroups per layer of this launch
 };
 
-template <int K, bool MUT>
+// what a report needs from its tie: the tie's rho and the LDS offset of the mirrored row
+template <int K>
+struct TieRho {
+  double r[K];
+  int moff;
+};
+template <int K>
+struct SumK {
+  double v[K];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = 0.0;
+  }
+};
+
+// common per-tile bookkeeping of the tile-pair kernels
+struct TileIter {
+  int I, J, nb, b, lb, bb, N;
+  __device__ __forceinline__ void init(const Geo& g, long long p0) {
+    nb = g.nb; b = g.b; lb = g.lb; bb = g.b * g.b; N = g.N;
+    pair_decode(p0, nb, I, J);
+  }
+  __device__ __forceinline__ void next() { if (++J == nb) { ++I; J = I; } }
+  __device__ __forceinline__ bool diag() const { return I == J; }
+  // tie slot tau -> (i,j); false when the slot is unused in this pair or lies outside the network
+  __device__ __forceinline__ bool coords(int tau, int& i, int& j) const {
+    const bool second = tau >= bb;
+    const int u = second ? tau - bb : tau;
+    const int p = u >> lb, q = u & (b - 1);
+    i = (second ? J : I) * b + p;
+    j = (second ? I : J) * b + q;
+    return tau < (diag() ? bb : 2 * bb) && i < N && j < N;
+  }
+  __device__ __forceinline__ int mirror(int tau) const {
+    const bool second = tau >= bb;
+    const int u = second ? tau - bb : tau;
+    const int m = ((u & (b - 1)) << lb) | (u >> lb);
+    return diag() ? m : (second ? m : bb + m);
+  }
+};
+
+template <int K, bool MUT, int PF>
 __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* S1 = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
   double* Gth = S1 + g.Mp;
   double* red = Gth + g.Mp;
+  double* wt = red + 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / g.Gl, gb = blockIdx.x - l * g.Gl;
-  const long long p0 = (long long)gb * g.P / g.Gl, p1 = (long long)(gb + 1) * g.P / g.Gl;
+  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
   for (int m = threadIdx.x; m < g.Mp; m += TPB) { S1[m] = 0.0; Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m]; }
   double Gla[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
   const double gnu = a.par[o.sc + SC_G_NU];
-  double Pk[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) Pk[k] = 0.0;
+  SumK<K> Pk;
+  Pk.zero();
+  __syncthreads();
+  if (MUT) build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
 
-  TileCtx t; t.N = g.N; t.b = g.b; t.lb = g.lb; t.bb = g.b * g.b;
-  int I, J;
-  pair_decode(p0, g.nb, I, J);
+  TileIter it;
+  it.init(g, p0);
   const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
   const uint8_t* Xl = a.X + (size_t)l * g.N * g.N * g.Mp;
   const double* rl = a.rho + (size_t)l * g.N * g.N * K;
+  TileStream<PF> ts;
+  ts.init(g);
+  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
-    t.I0 = I * g.b; t.J0 = J * g.b; t.diag = (I == J);
-    const int nt_cur = t.diag ? t.bb : 2 * t.bb;
-    load_tile(Xl, xt, g, t, nt_cur);
+    ts.store(xt);
     int i, j;
-    const bool act = tau < nt_cur && tie_coords(t, tau, i, j);
-    double r[K];
-    if (act) {
+    const bool act = it.coords(tau, i, j);
+    TieRho<K> own;
+    own.moff = it.mirror(tau) * g.stride;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r[k] = rl[((size_t)i * g.N + j) * K + k];
-    }
+    for (int k = 0; k < K; ++k) own.r[k] = act ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
     __syncthreads();
-    if (act) {
-      const unsigned char* row = xt + tau * g.stride;
-      const unsigned char* mrow = xt + mirror_slot(t, tau) * g.stride;
-      scan_row(row, s, g.S, g.nchunk, [&](int m, unsigned x) {
-        double dx = (double)x, sum = 0.0;
-        if (MUT) {
-          unsigned y = mrow[m];
-          if (y == 0) {
+    it.next();
+    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);   // flies while this pair is scanned
+    if (!(g.dbg & 2)) {
+      scan_tie(xt, g, tau, s, act, own, Pk,
+        [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
+          if (g.dbg & 1) { acc.v[0] += (double)x; return; }
+          double dx = (double)x, sum = 0.0;
+          if (MUT) {
+            double w[K];
+            weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, (unsigned)xt[c.moff + m]);
 #pragma unroll
-            for (int k = 0; k < K; ++k) sum += r[k] * ((Gth[m] * Gla[k] != 0.0) ? 1.0 : 0.0);
+            for (int k = 0; k < K; ++k) sum += c.r[k] * w[k];
           } else {
-            double z2 = gnu * (double)y;
 #pragma unroll
-            for (int k = 0; k < K; ++k) sum += r[k] * w1_of(Gth[m] * Gla[k], z2);
+            for (int k = 0; k < K; ++k) { sum += c.r[k]; acc.v[k] += dx * c.r[k]; }
           }
-        } else {
+          atomicAdd(&S1[m], dx * sum);
+        },
+        [&](int h) {
+          TieRho<K> c;
+          c.moff = __builtin_amdgcn_readlane(own.moff, h);
 #pragma unroll
-          for (int k = 0; k < K; ++k) { sum += r[k]; Pk[k] += dx * r[k]; }
-        }
-        atomicAdd(&S1[m], dx * sum);
-      });
+          for (int k = 0; k < K; ++k) c.r[k] = readlane_f64(own.r[k], h);
+          return c;
+        },
+        [&](int, const SumK<K>& t) {   // block-wide sums: any lane may keep the helpers' share
+#pragma unroll
+          for (int k = 0; k < K; ++k) Pk.v[k] += t.v[k];
+        });
     }
     __syncthreads();
-    if (++J == g.nb) { ++I; J = I; }
   }
-  for (int m = threadIdx.x; m < g.Mp; m += TPB) a.partS1[(size_t)blockIdx.x * g.Mp + m] = S1[m];
-  if (!MUT) {
+  double* oS = a.slotS1 + ((size_t)l * NSLOT + (gb % NSLOT)) * g.Mp;
+  for (int m = threadIdx.x; m < g.M; m += TPB) atomicAdd(&oS[m], S1[m]);
+  if (!MUT || g.dbg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      double v = block_sum(Pk[k], red);
-      if (threadIdx.x == 0) a.partP[(size_t)blockIdx.x * K + k] = v;
+      double v = block_sum(Pk.v[k], red);
+      if (threadIdx.x == 0 && !MUT) atomicAdd(&a.slotP[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
     }
   }
 }
@@ -473,95 +690,130 @@ __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
 // phi, counts (mutuality on; model.py:731-733, 861-887): P[l,k] = sum x rho_k w1_k with the
 // NEW E[log theta] -- the cache refresh of model.py:647 sits between the two updates.
 // ------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int PF>
 __global__ __launch_bounds__(TPB, 4) void k_phi(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* Gth = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
   double* red = Gth + g.Mp;
+  double* wt = red + 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / g.Gl, gb = blockIdx.x - l * g.Gl;
-  const long long p0 = (long long)gb * g.P / g.Gl, p1 = (long long)(gb + 1) * g.P / g.Gl;
+  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
   for (int m = threadIdx.x; m < g.Mp; m += TPB) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
-  double Gla[K], Pk[K];
+  double Gla[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { Gla[k] = a.par[o.G_la + l * K + k]; Pk[k] = 0.0; }
+  for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
   const double gnu = a.par[o.sc + SC_G_NU];
-  TileCtx t; t.N = g.N; t.b = g.b; t.lb = g.lb; t.bb = g.b * g.b;
-  int I, J;
-  pair_decode(p0, g.nb, I, J);
+  SumK<K> Pk;
+  Pk.zero();
+  __syncthreads();
+  build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
+  TileIter it;
+  it.init(g, p0);
   const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
   const uint8_t* Xl = a.X + (size_t)l * g.N * g.N * g.Mp;
   const double* rl = a.rho + (size_t)l * g.N * g.N * K;
+  TileStream<PF> ts;
+  ts.init(g);
+  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
-    t.I0 = I * g.b; t.J0 = J * g.b; t.diag = (I == J);
-    const int nt_cur = t.diag ? t.bb : 2 * t.bb;
-    load_tile(Xl, xt, g, t, nt_cur);
+    ts.store(xt);
     int i, j;
-    const bool act = tau < nt_cur && tie_coords(t, tau, i, j);
-    double r[K];
-    if (act) {
+    const bool act = it.coords(tau, i, j);
+    TieRho<K> own;
+    own.moff = it.mirror(tau) * g.stride;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r[k] = rl[((size_t)i * g.N + j) * K + k];
+    for (int k = 0; k < K; ++k) own.r[k] = act ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
+    __syncthreads();
+    it.next();
+    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+    if (!(g.dbg & 2)) {
+      scan_tie(xt, g, tau, s, act, own, Pk,
+        [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
+          if (g.dbg & 1) { acc.v[0] += (double)x; return; }
+          double dx = (double)x, w[K];
+          weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, (unsigned)xt[c.moff + m]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc.v[k] += dx * c.r[k] * w[k];
+        },
+        [&](int h) {
+          TieRho<K> c;
+          c.moff = __builtin_amdgcn_readlane(own.moff, h);
+#pragma unroll
+          for (int k = 0; k < K; ++k) c.r[k] = readlane_f64(own.r[k], h);
+          return c;
+        },
+        [&](int, const SumK<K>& t) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) Pk.v[k] += t.v[k];
+        });
     }
     __syncthreads();
-    if (act) {
-      const unsigned char* row = xt + tau * g.stride;
-      const unsigned char* mrow = xt + mirror_slot(t, tau) * g.stride;
-      scan_row(row, s, g.S, g.nchunk, [&](int m, unsigned x) {
-        double dx = (double)x;
-        unsigned y = mrow[m];
-        if (y == 0) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) Pk[k] += dx * r[k] * ((Gth[m] * Gla[k] != 0.0) ? 1.0 : 0.0);
-        } else {
-          double z2 = gnu * (double)y;
-#pragma unroll
-          for (int k = 0; k < K; ++k) Pk[k] += dx * r[k] * w1_of(Gth[m] * Gla[k], z2);
-        }
-      });
-    }
-    __syncthreads();
-    if (++J == g.nb) { ++I; J = I; }
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    double v = block_sum(Pk[k], red);
-    if (threadIdx.x == 0) a.partP[(size_t)blockIdx.x * K + k] = v;
+    double v = block_sum(Pk.v[k], red);
+    if (threadIdx.x == 0) atomicAdd(&a.slotP[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // rho (+ nu partial, + ELBO data terms)   model.py:763-830, 889-923, 948-995, 1013
-// partR per workgroup: [0] nu partial, [1] ELBO linear+entropy terms, [2] ELBO log terms,
-//                      [3] sum_t (sum_k rho_k) Q_t  (multiplied by -E[nu] in k_fin_rho)
+// slotR[slot][4]: [0] nu partial, [1] ELBO linear+entropy terms, [2] ELBO log terms,
+//                 [3] sum_t (sum_k rho_k) Q_t  (multiplied by -E[nu] in k_fin_rho)
+// One scan of the tile serves rho AND nu: per tie V_k = sum_{reports with a mirror count} x w2_k
+// is collected next to U_k, and sum_k rho_new_k V_k is the tie's share of nu_shp (model.py:822-825).
 // ------------------------------------------------------------------------------------------
 struct RhoArgs {
   const uint8_t* X; const uint64_t* Rb; double* rho; const double* logpr; const double* par;
-  double* partR;
+  double* slotR;
+  int Gl;
 };
 
-template <int K, bool MUT, bool UPDATE, bool ELBO>
-__global__ __launch_bounds__(TPB, 2) void k_rho(RhoArgs a, Geo g) {
+struct TieMirror { int moff; };   // rho update: a report only needs the mirrored row
+template <int K>
+struct TieElbo {                  // ELBO: exp(rho) of the tie, its mask row and the mirror's
+  double er[K];
+  int moff, roff, rmoff, mtau;
+};
+template <int K>
+struct SumUV {
+  double U[K], V[K];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { U[k] = 0.0; V[k] = 0.0; }
+  }
+};
+struct Sum1 {
+  double v;
+  __device__ __forceinline__ void zero() { v = 0.0; }
+};
+
+template <int K, bool MUT, bool UPDATE, bool ELBO, int PF>
+__global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   size_t off = (size_t)g.nt * g.stride;
   uint64_t* rw = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)g.nt * g.W * 8;
   double* lut = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 16 * 16 * 8;
+  double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* Gth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
+  double* wt = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)(YT + 1) * g.Mp * K * 8 : 0;
   unsigned* qs = reinterpret_cast<unsigned*>(smem + off);
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / g.Gl, gb = blockIdx.x - l * g.Gl;
-  const long long p0 = (long long)gb * g.P / g.Gl, p1 = (long long)(gb + 1) * g.P / g.Gl;
+  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
   const double* Eth = a.par + o.E_th + (size_t)l * g.Mp;
   for (int m = threadIdx.x; m < g.Mp; m += TPB) {
     lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
     Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
   }
-  // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3
+  // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3;
+  // wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
   for (int q = threadIdx.x; q < g.W * 16 * 16; q += TPB) {
     int n = q >> 4, e = q & 15;
     double v = 0.0;
@@ -580,148 +832,171 @@ __global__ __launch_bounds__(TPB, 2) void k_rho(RhoArgs a, Geo g) {
   // UPDATE: the weights use the current G_nu; stand-alone ELBO: the stale one (model.py:970)
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];
   const double eps = g.eps;
-  double nu_acc = 0.0, e_lin = 0.0, e_log = 0.0, e_q = 0.0;
+  double nu_acc = 0.0, e_lin = 0.0, e_q = 0.0;
+  Sum1 e_log;
+  e_log.zero();
+  __syncthreads();
+  for (int w = threadIdx.x; w < g.W; w += TPB) {
+    double v = 0.0;
+    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
+    wsum[w] = v;
+  }
+  if (MUT) build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
 
-  TileCtx t; t.N = g.N; t.b = g.b; t.lb = g.lb; t.bb = g.b * g.b;
-  int I, J;
-  pair_decode(p0, g.nb, I, J);
-  const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
+  TileIter it;
+  it.init(g, p0);
+  const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1), lane = threadIdx.x & 63;
   const size_t T = (size_t)g.N * g.N;
   const uint8_t* Xl = a.X + (size_t)l * T * g.Mp;
   const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
   double* rl = a.rho + (size_t)l * T * K;
   const double* lpl = a.logpr + (size_t)l * T * K;
-  const int nnib = g.W * 16;
+  TileStream<PF> ts;
+  ts.init(g);
+  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
-    t.I0 = I * g.b; t.J0 = J * g.b; t.diag = (I == J);
-    const int nt_cur = t.diag ? t.bb : 2 * t.bb;
-    load_tile(Xl, xt, g, t, nt_cur);
+    ts.store(xt);
+    const int nt_cur = it.diag() ? it.bb : 2 * it.bb;
     for (int q = threadIdx.x; q < nt_cur * g.W; q += TPB) {
       int tq = q / g.W, w = q - tq * g.W, i2, j2;
-      rw[q] = tie_coords(t, tq, i2, j2) ? Rl[((size_t)i2 * g.N + j2) * g.W + w] : 0ull;
+      rw[q] = it.coords(tq, i2, j2) ? Rl[((size_t)i2 * g.N + j2) * g.W + w] : 0ull;
     }
+    if (ELBO) { for (int q = threadIdx.x; q < g.nt; q += TPB) qs[q] = 0u; }
     int i, j;
-    const bool act = tau < nt_cur && tie_coords(t, tau, i, j);
+    const bool act = it.coords(tau, i, j);
     const size_t tg = act ? ((size_t)i * g.N + j) : 0;
+    const int mtau = it.mirror(tau);
     double lp[K], r[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { lp[k] = 0.0; r[k] = 0.0; }
-    if (act) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        lp[k] = lpl[tg * K + k];
-        if (!UPDATE) r[k] = rl[tg * K + k];
-      }
+    for (int k = 0; k < K; ++k) {
+      lp[k] = act ? lpl[tg * K + k] : 0.0;
+      r[k] = (!UPDATE && act) ? rl[tg * K + k] : 0.0;
     }
     __syncthreads();
-    const int mtau = act ? mirror_slot(t, tau) : 0;
-    const unsigned char* row = xt + tau * g.stride;
-    const unsigned char* mrow = xt + mtau * g.stride;
+    it.next();
+    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
     double Tt = 0.0;
     if (act) {
-      // T = sum_m R E[theta_m] (model.py:766-792) by nibble look-up
-      const unsigned char* rb = reinterpret_cast<const unsigned char*>(rw + (size_t)tau * g.W);
-      for (int n = s; n < nnib; n += g.S) {
-        unsigned nib = (rb[n >> 1] >> ((n & 1) * 4)) & 15u;
-        Tt += lut[n * 16 + nib];
+      // T = sum_m R E[theta_m] (model.py:766-792): whole-word shortcut, else nibble look-ups
+      const uint64_t* rwt = rw + (size_t)tau * g.W;
+      for (int w = s; w < g.W; w += g.S) {
+        uint64_t bits = rwt[w];
+        if (bits == ~0ull) { Tt += wsum[w]; continue; }
+        for (int n = 0; bits != 0; ++n, bits >>= 4) Tt += lut[((w * 16 + n) << 4) + (unsigned)(bits & 15u)];
       }
     }
     Tt = group_sum(Tt, g.S);
     if (UPDATE) {
-      double U[K];
+      SumUV<K> uv;
+      uv.zero();
+      TieMirror own;
+      own.moff = mtau * g.stride;
+      if (!(g.dbg & 2)) {
+        scan_tie(xt, g, tau, s, act, own, uv,
+          [&](int m, unsigned x, const TieMirror& c, SumUV<K>& acc) {
+            if (g.dbg & 1) { acc.U[0] += (double)x; return; }
+            const double dx = (double)x, lt = lth[m];
+            if (MUT) {
+              const unsigned y = xt[c.moff + m];
+              double w[K];
+              weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, y);
 #pragma unroll
-      for (int k = 0; k < K; ++k) U[k] = 0.0;
-      if (act) {
-        scan_row(row, s, g.S, g.nchunk, [&](int m, unsigned x) {
-          double dx = (double)x;
-          unsigned y = MUT ? (unsigned)mrow[m] : 0u;
-          if (y == 0) {
+              for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * (dx * w[k]);
+              if (y != 0) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) U[k] += (lth[m] + lla[k]) * (dx * ((!MUT || Gth[m] * Gla[k] != 0.0) ? 1.0 : 0.0));
-          } else {
-            double z2 = gnu * (double)y;
+                for (int k = 0; k < K; ++k) acc.V[k] += dx * (1.0 - w[k]);   // x w2_k, model.py:694-696
+              }
+            } else {
 #pragma unroll
-            for (int k = 0; k < K; ++k) U[k] += (lth[m] + lla[k]) * (dx * w1_of(Gth[m] * Gla[k], z2));
-          }
-        });
+              for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * dx;
+            }
+          },
+          [&](int h) {
+            TieMirror c;
+            c.moff = __builtin_amdgcn_readlane(own.moff, h);
+            return c;
+          },
+          [&](int h, const SumUV<K>& t) {   // per-tie sums: reduce the helpers' shares, give them to lane h
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              double su = wave_sum(t.U[k]), sv = MUT ? wave_sum(t.V[k]) : 0.0;
+              if (lane == h) { uv.U[k] += su; uv.V[k] += sv; }
+            }
+          });
       }
       double sum = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        U[k] = group_sum(U[k], g.S);
-        r[k] = exp((lp[k] + U[k]) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
+        double u = group_sum(uv.U[k], g.S);
+        r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
         sum += r[k];
       }
-      if (sum > 0.0) {
+      if (sum > 0.0) {   // model.py:808-811
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] /= sum;
       }
-      if (act && s == 0) {
+      if (act) {
+        if (s == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) rl[tg * K + k] = r[k];
+          for (int k = 0; k < K; ++k) rl[tg * K + k] = r[k];
+        }
+        if (MUT) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) nu_acc += uv.V[k] * r[k];   // this lane's share of model.py:822-825
+        }
       }
     }
-    if ((UPDATE && MUT) || ELBO) {
-      unsigned qloc = 0;
-      if (act) {
-        double er[K];
-        if (ELBO) {
+    if (ELBO) {
+      TieElbo<K> own;
 #pragma unroll
-          for (int k = 0; k < K; ++k) er[k] = exp(r[k]);   // exp(rho), model.py:971
+      for (int k = 0; k < K; ++k) own.er[k] = exp(r[k]);   // exp(rho), model.py:971
+      own.moff = mtau * g.stride; own.roff = tau * g.W; own.rmoff = mtau * g.W; own.mtau = mtau;
+      scan_tie(xt, g, tau, s, act, own, e_log,
+        [&](int m, unsigned x, const TieElbo<K>& c, Sum1& acc) {
+          const double dx = (double)x;
+          const unsigned y = MUT ? (unsigned)xt[c.moff + m] : 0u;
+          const bool in_r = (rw[c.roff + (m >> 6)] >> (m & 63)) & 1ull;
+          double inner = 0.0;
+          if (in_r) {
+            const double z2 = gnu * (double)y;
+#pragma unroll
+            for (int k = 0; k < K; ++k) inner += c.er[k] * (Gth[m] * Gla[k] + z2);
+          }
+          acc.v += dx * log(inner + eps);
+          if (MUT && ((rw[c.rmoff + (m >> 6)] >> (m & 63)) & 1ull)) atomicAdd(&qs[c.mtau], x);   // R[mirror] X^T[mirror]
+        },
+        [&](int h) {
+          TieElbo<K> c;
+#pragma unroll
+          for (int k = 0; k < K; ++k) c.er[k] = readlane_f64(own.er[k], h);
+          c.moff = __builtin_amdgcn_readlane(own.moff, h); c.roff = __builtin_amdgcn_readlane(own.roff, h);
+          c.rmoff = __builtin_amdgcn_readlane(own.rmoff, h); c.mtau = __builtin_amdgcn_readlane(own.mtau, h);
+          return c;
+        },
+        [&](int, const Sum1& t) { e_log.v += t.v; });
+      __syncthreads();
+      if (act && s == 0) {
+        double sr = 0.0, se = 0.0, ent = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          sr += r[k]; se += r[k] * Ela[k];
+          ent += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
         }
-        const uint64_t* rwt = rw + (size_t)tau * g.W;
-        const uint64_t* rwm = rw + (size_t)mtau * g.W;
-        scan_row(row, s, g.S, g.nchunk, [&](int m, unsigned x) {
-          double dx = (double)x;
-          unsigned y = MUT ? (unsigned)mrow[m] : 0u;
-          if (UPDATE && MUT && y != 0) {
-            double z2 = gnu * (double)y;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              double z1 = Gth[m] * Gla[k];
-              nu_acc += dx * (z2 / (z1 + z2)) * r[k];   // x w2_k rho_k, model.py:694-696, 822-825
-            }
-          }
-          if (ELBO) {
-            bool in_r = (rwt[m >> 6] >> (m & 63)) & 1ull;
-            double inner = 0.0;
-            if (in_r) {
-              double z2 = gnu * (double)y;
-#pragma unroll
-              for (int k = 0; k < K; ++k) inner += er[k] * (Gth[m] * Gla[k] + z2);
-            }
-            e_log += dx * log(inner + eps);
-            if (MUT && ((rwm[m >> 6] >> (m & 63)) & 1ull)) qloc += x;   // R[mirror] * X^T[mirror]
-          }
-        });
-      }
-      if (ELBO) {
-        qloc = group_sum_u(qloc, g.S);
-        if (act && s == 0) qs[mtau] = qloc;
-        __syncthreads();
-        if (act && s == 0) {
-          double sr = 0.0, se = 0.0, ent = 0.0;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            sr += r[k]; se += r[k] * Ela[k];
-            ent += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
-          }
-          e_lin += ent - se * Tt;
-          e_q += sr * (double)qs[tau];
-        }
+        e_lin += ent - se * Tt;
+        e_q += sr * (double)qs[tau];
       }
     }
     __syncthreads();
-    if (++J == g.nb) { ++I; J = I; }
   }
   double v0 = block_sum(nu_acc, red);
   double v1 = block_sum(e_lin, red);
-  double v2 = block_sum(e_log, red);
+  double v2 = block_sum(e_log.v, red);
   double v3 = block_sum(e_q, red);
   if (threadIdx.x == 0) {
-    double* out = a.partR + (size_t)blockIdx.x * 4;
-    out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3;
+    double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+    if (UPDATE && MUT) atomicAdd(&out[0], v0);
+    if (ELBO) { atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3); }
   }
 }
 
@@ -730,9 +1005,7 @@ __global__ __launch_bounds__(TPB, 2) void k_rho(RhoArgs a, Geo g) {
 // ------------------------------------------------------------------------------------------
 // gamma_shp/rte (model.py:700-718), then phi_rte from the same A with the new E[theta]
 // (model.py:742-749); mutuality off: phi_shp too, and commit phi.
-__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ partS1,
-                                                   const double* __restrict__ partA, const double* __restrict__ partP,
-                                                   Geo g) {
+__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, double* slotS1, double* slotA, double* slotP, Geo g) {
   __shared__ double red[8];
   __shared__ double ela_old[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
@@ -743,11 +1016,17 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
   for (int k = 0; k < KMAX; ++k) pr[k] = 0.0;
   for (int m = threadIdx.x; m < g.M; m += TPB) {
     double s1 = 0.0;
-    for (int gb = 0; gb < g.Gl; ++gb) s1 += partS1[((size_t)l * g.Gl + gb) * g.Mp + m];
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      double* ps = &slotS1[((size_t)l * NSLOT + sl) * g.Mp + m];
+      s1 += *ps; *ps = 0.0;   // consume: the slots are zero again for the next sweep
+    }
     double A[KMAX], rte = 0.0;
     for (int k = 0; k < K; ++k) {
       double ak = 0.0;
-      for (int gb = 0; gb < g.Gm; ++gb) ak += partA[(((size_t)l * g.Gm + gb) * Wp + m) * K + k];
+      for (int sl = 0; sl < NSLOT; ++sl) {
+        double* pa = &slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];
+        ak += *pa; *pa = 0.0;
+      }
       A[k] = ak;
       rte += ela_old[k] * ak;
     }
@@ -767,7 +1046,10 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
         par[o.p_rte_pend + l * K + k] = rte;
       } else {
         double ps = 0.0;
-        for (int gb = 0; gb < g.Gl; ++gb) ps += partP[((size_t)l * g.Gl + gb) * K + k];
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          double* pp = &slotP[((size_t)l * NSLOT + sl) * K + k];
+          ps += *pp; *pp = 0.0;
+        }
         double shp = par[o.a_la + l * K + k] + ps;
         par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
         double lg = digamma_pos(shp) - log(rte);
@@ -778,13 +1060,16 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
 }
 
 // phi commit, mutuality on (model.py:731-749)
-__global__ void k_fin_phi(double* par, const double* __restrict__ partP, Geo g) {
+__global__ void k_fin_phi(double* par, double* slotP, Geo g) {
   const ParOff o = par_off(g.L, g.Mp, g.K);
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= g.L * g.K) return;
   int l = q / g.K, k = q - l * g.K;
   double ps = 0.0;
-  for (int gb = 0; gb < g.Gl; ++gb) ps += partP[((size_t)l * g.Gl + gb) * g.K + k];
+  for (int sl = 0; sl < NSLOT; ++sl) {
+    double* pp = &slotP[((size_t)l * NSLOT + sl) * g.K + k];
+    ps += *pp; *pp = 0.0;
+  }
   double shp = par[o.a_la + q] + ps, rte = par[o.p_rte_pend + q];
   par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
   double lg = digamma_pos(shp) - log(rte);
@@ -797,15 +1082,16 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 }
 
 // nu commit (model.py:822-825) and/or ELBO assembly (model.py:997-1013)
-__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, const double* __restrict__ partR, double* elbo_out,
-                                                 int nblocks, int do_nu, int do_elbo, Geo g) {
+__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* slotR, double* elbo_out, int do_nu, int do_elbo,
+                                                 Geo g) {
   __shared__ double red[8];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  for (int q = threadIdx.x; q < nblocks; q += TPB) {
-    a0 += partR[(size_t)q * 4 + 0]; a1 += partR[(size_t)q * 4 + 1];
-    a2 += partR[(size_t)q * 4 + 2]; a3 += partR[(size_t)q * 4 + 3];
+  if (threadIdx.x < NSLOT) {
+    double* ps = slotR + (size_t)threadIdx.x * 4;
+    a0 = ps[0]; a1 = ps[1]; a2 = ps[2]; a3 = ps[3];
+    ps[0] = ps[1] = ps[2] = ps[3] = 0.0;   // consume
   }
   a0 = block_sum(a0, red); a1 = block_sum(a1, red); a2 = block_sum(a2, red); a3 = block_sum(a3, red);
   double gt = 0.0;
@@ -839,11 +1125,12 @@ static int fail(vmr_handle h, int code, const char* msg) {
   return code;
 }
 
-static size_t shmem_counts(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 16 + 64; }
-static size_t shmem_phi(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64; }
+static size_t shmem_wt(const Geo& g) { return g.mut ? (size_t)(YT + 1) * g.Mp * g.K * 8 : 0; }
+static size_t shmem_counts(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 16 + 64 + shmem_wt(g); }
+static size_t shmem_phi(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + shmem_wt(g); }
 static size_t shmem_rho(const Geo& g) {
-  return (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.Mp * 16 + 64 +
-         (size_t)g.nt * 4 + 16;
+  return (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.W * 8 +
+         (size_t)g.Mp * 16 + 64 + shmem_wt(g) + (size_t)g.nt * 4 + 16;
 }
 
 struct Prof {
@@ -856,6 +1143,13 @@ struct Prof {
   }
 };
 
+#ifdef VMR_DEV   // development build: K = 2 only (fast compile, ISA inspection)
+#define DISPATCH_K(K_, ...)                         \
+  switch (K_) {                                     \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; } break; \
+    default: break;                                 \
+  }
+#else
 #define DISPATCH_K(K_, ...)                         \
   switch (K_) {                                     \
     case 2: { constexpr int KK = 2; __VA_ARGS__; } break; \
@@ -867,34 +1161,63 @@ struct Prof {
     case 8: { constexpr int KK = 8; __VA_ARGS__; } break; \
     default: break;                                 \
   }
+#endif
+// K and the prefetch depth (4, 8 or 12 sixteen-byte chunks per thread)
+#define DISPATCH_KP(K_, PF_, ...)                                     \
+  switch (PF_) {                                                      \
+    case 4: { constexpr int PP = 4; DISPATCH_K(K_, __VA_ARGS__); } break;   \
+    case 8: { constexpr int PP = 8; DISPATCH_K(K_, __VA_ARGS__); } break;   \
+    default: { constexpr int PP = 12; DISPATCH_K(K_, __VA_ARGS__); } break; \
+  }
 
+// Opt in to > 48 KB of dynamic LDS and size the (persistent) grid to what is resident at once:
+// workgroups per layer = resident workgroups per CU x CUs / L, never more than tile pairs.
 template <class Kern>
-static hipError_t set_smem(Kern k, size_t bytes) {
-  if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return hipSuccess;
+static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
+  const void* fn = reinterpret_cast<const void*>(k);
+  int per_cu = 0;
+  for (auto& e : h->occ) if (e.first == fn) per_cu = e.second;
+  if (!per_cu) {
+    if (smem > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TPB, smem));
+    if (per_cu < 1) per_cu = 1;
+    h->occ.push_back({fn, per_cu});
+  }
+  long long gl_ = (long long)per_cu * h->ncu / h->g.L;
+  if (gl_ < 1) gl_ = 1;
+  if (gl_ > h->g.P) gl_ = h->g.P;
+  *gl = (int)gl_;
+  return VMR_OK;
 }
 
 static int launch_gamma(vmr_ctx* h) {
   const Geo& g = h->g;
   {
     Prof p(h, VMR_KERNEL_GAMMA_MASK);
-    DISPATCH_K(g.K, hipLaunchKernelGGL(k_gamma_mask<KK>, dim3(g.L * g.Gm), dim3(TPB), 0, h->stream, h->Rb, h->rho, h->partA, g));
+    dim3 grid(g.L * g.Gm), blk(TPB);
+    switch (g.W >= 4 ? 4 : g.W) {
+      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
+      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
+      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
+      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
+    }
   }
   {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
-    CountArgs a{h->X, h->rho, h->par, h->partS1, h->partP};
+    CountArgs a{h->X, h->rho, h->par, h->slotS1, h->slotP, 1};
     size_t sm = shmem_counts(g);
+    int rc = VMR_OK;
     if (g.mut) {
-      DISPATCH_K(g.K, HIPCHK(h, set_smem(k_gamma_counts<KK, true>, sm));
-                 hipLaunchKernelGGL((k_gamma_counts<KK, true>), dim3(g.L * g.Gl), dim3(TPB), sm, h->stream, a, g));
+      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_gamma_counts<KK, true, PP>, sm, &a.Gl))) return rc;
+                  hipLaunchKernelGGL((k_gamma_counts<KK, true, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
     } else {
-      DISPATCH_K(g.K, HIPCHK(h, set_smem(k_gamma_counts<KK, false>, sm));
-                 hipLaunchKernelGGL((k_gamma_counts<KK, false>), dim3(g.L * g.Gl), dim3(TPB), sm, h->stream, a, g));
+      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_gamma_counts<KK, false, PP>, sm, &a.Gl))) return rc;
+                  hipLaunchKernelGGL((k_gamma_counts<KK, false, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
     }
   }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->partS1, h->partA, h->partP, g);
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->slotS1, h->slotA, h->slotP, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -905,15 +1228,16 @@ static int launch_phi(vmr_ctx* h) {
   if (!g.mut) return VMR_OK;   // committed by k_fin_gamma
   {
     Prof p(h, VMR_KERNEL_PHI);
-    CountArgs a{h->X, h->rho, h->par, h->partS1, h->partP};
+    CountArgs a{h->X, h->rho, h->par, h->slotS1, h->slotP, 1};
     size_t sm = shmem_phi(g);
-    DISPATCH_K(g.K, HIPCHK(h, set_smem(k_phi<KK>, sm));
-               hipLaunchKernelGGL(k_phi<KK>, dim3(g.L * g.Gl), dim3(TPB), sm, h->stream, a, g));
+    int rc = VMR_OK;
+    DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_phi<KK, PP>, sm, &a.Gl))) return rc;
+                hipLaunchKernelGGL((k_phi<KK, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
   }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     int n = g.L * g.K;
-    hipLaunchKernelGGL(k_fin_phi, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->par, h->partP, g);
+    hipLaunchKernelGGL(k_fin_phi, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->par, h->slotP, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -922,14 +1246,18 @@ static int launch_phi(vmr_ctx* h) {
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   const Geo& g = h->g;
-  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->partR};
+  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, 1};
   size_t sm = shmem_rho(g);
-  dim3 grid(g.L * g.Gl), blk(TPB);
+  dim3 blk(TPB);
+  int rc = VMR_OK;
+  // the nu sub-step may be skipped by a caller: start from clean slots when nobody consumed them
+  if (h->slotR_dirty) HIPCHK(h, hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
+  h->slotR_dirty = (mode == 0 && !commit_nu);
   {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : VMR_KERNEL_RHO);
-#define LRHO(MUT_, UPD_, ELB_)                                                            \
-  DISPATCH_K(g.K, HIPCHK(h, set_smem(k_rho<KK, MUT_, UPD_, ELB_>, sm));                    \
-             hipLaunchKernelGGL((k_rho<KK, MUT_, UPD_, ELB_>), grid, blk, sm, h->stream, a, g))
+#define LRHO(MUT_, UPD_, ELB_)                                                                  \
+  DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_rho<KK, MUT_, UPD_, ELB_, PP>, sm, &a.Gl))) return rc; \
+              hipLaunchKernelGGL((k_rho<KK, MUT_, UPD_, ELB_, PP>), dim3(g.L * a.Gl), blk, sm, h->stream, a, g))
     if (g.mut) {
       if (mode == 0) { LRHO(true, true, false); } else if (mode == 1) { LRHO(true, true, true); } else { LRHO(true, false, true); }
     } else {
@@ -937,9 +1265,9 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     }
 #undef LRHO
   }
-  {
+  if (mode != 0 || commit_nu) {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->partR, h->elbo_dev, g.L * g.Gl,
+    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev,
                        (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0, g);
   }
   HIPCHK(h, hipGetLastError());
@@ -954,20 +1282,22 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   const size_t budget = 48 * 1024;
   int b = 8;
   while (b > 1 && (size_t)2 * b * b * g.stride > budget) b >>= 1;
-  if ((size_t)2 * b * b * g.stride > 96 * 1024) { err = "M too large for the LDS tile (M <= ~49000 supported)"; return VMR_EINVAL; }
+  if ((size_t)2 * b * b * g.stride > budget) { err = "M too large for the LDS tile (M <= ~24500 supported)"; return VMR_EINVAL; }
   g.b = b; g.lb = (b == 8) ? 3 : (b == 4) ? 2 : (b == 2) ? 1 : 0;
   g.nb = (g.N + b - 1) / b;
   g.nt = 2 * b * b;
   g.S = TPB / g.nt; if (g.S > 64) g.S = 64;
   g.lS = 0; while ((1 << g.lS) < g.S) ++g.lS;
   g.P = (long long)g.nb * (g.nb + 1) / 2;
-  int target = ncu * 4;
-  long long gl = target / g.L; if (gl < 1) gl = 1; if (gl > g.P) gl = g.P;
-  g.Gl = (int)gl;
+  g.Gl = 0;   // per launch, see grid_per_layer()
   long long T = (long long)g.N * g.N;
-  long long gm = target / g.L; if (gm < 1) gm = 1;
+  long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
   g.Gm = (int)gm;
+  int need = (g.nt * g.nchunk + TPB - 1) / TPB;
+  g.pf = need <= 4 ? 4 : need <= 8 ? 8 : 12;
+  const char* dbg = getenv("VMR_DEBUG");
+  g.dbg = dbg ? atoi(dbg) : 0;
   return VMR_OK;
 }
 
@@ -1001,7 +1331,10 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t rows = (size_t)L * N * N;
   const size_t raw = rows * M;
-  CCHK(hipMalloc(&h->X, rows * g.Mp));
+  h->ncu = prop.multiProcessorCount;
+  const size_t slack = (size_t)g.b * N + g.b;   // tile streams may read (never use) rows past the last tie
+  CCHK(hipMalloc(&h->X, (rows + slack) * g.Mp));
+  CCHK(hipMemsetAsync(h->X + rows * g.Mp, 0, slack * g.Mp, h->stream));
   CCHK(hipMalloc(&h->Rb, rows * g.W * 8));
   CCHK(hipMalloc(&h->cov, rows));
   CCHK(hipMalloc(&h->sumx, 8));
@@ -1026,10 +1359,13 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   h->par_doubles = o.total;
   CCHK(hipMalloc(&h->par, o.total * 8));
   CCHK(hipMemsetAsync(h->par, 0, o.total * 8, h->stream));
-  CCHK(hipMalloc(&h->partS1, (size_t)L * g.Gl * g.Mp * 8));
-  CCHK(hipMalloc(&h->partA, (size_t)L * g.Gm * g.W * 64 * K * 8));
-  CCHK(hipMalloc(&h->partP, (size_t)L * g.Gl * K * 8));
-  CCHK(hipMalloc(&h->partR, (size_t)L * g.Gl * 4 * 8));
+  {
+    size_t nS1 = (size_t)L * NSLOT * g.Mp * 8, nA = (size_t)L * NSLOT * g.W * 64 * K * 8, nP = (size_t)L * NSLOT * K * 8;
+    CCHK(hipMalloc(&h->slotS1, nS1)); CCHK(hipMemsetAsync(h->slotS1, 0, nS1, h->stream));
+    CCHK(hipMalloc(&h->slotA, nA)); CCHK(hipMemsetAsync(h->slotA, 0, nA, h->stream));
+    CCHK(hipMalloc(&h->slotP, nP)); CCHK(hipMemsetAsync(h->slotP, 0, nP, h->stream));
+    CCHK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CCHK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
+  }
   CCHK(hipMalloc(&h->elbo_dev, 8 * 8));
   CCHK(hipStreamSynchronize(h->stream));
 #undef CCHK
@@ -1042,7 +1378,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->partS1, h->partA, h->partP, h->partR, h->elbo_dev};
+  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotS1, h->slotA, h->slotP, h->slotR, h->elbo_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1163,8 +1499,8 @@ int vmr_sub_step(vmr_handle h, int which) {
     case VMR_STEP_NU: {
       if (!h->g.mut) return VMR_OK;
       Prof p(h, VMR_KERNEL_FINALIZE);
-      hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->partR, h->elbo_dev,
-                         h->g.L * h->g.Gl, 1, 0, h->g);
+      hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev, 1, 0, h->g);
+      h->slotR_dirty = false;
       HIPCHK(h, hipGetLastError());
       return VMR_OK;
     }
