@@ -44,10 +44,11 @@ enum {
   VMR_KERNEL_GAMMA_MASK = 0,   /* masked reduction over R: A[l,m,k] = sum_ij R rho           */
   VMR_KERNEL_GAMMA_COUNTS = 1, /* sweep over X for gamma_shp (and phi_shp when mutuality off) */
   VMR_KERNEL_PHI = 2,          /* sweep over X for phi_shp (mutuality on)                     */
-  VMR_KERNEL_RHO = 3,          /* sweep over X,R: rho update (+ nu partial, + fused ELBO)     */
+  VMR_KERNEL_RHO = 3,          /* sweep over X,R: rho update (+ nu partial)                   */
   VMR_KERNEL_ELBO = 4,         /* stand-alone ELBO sweep                                      */
   VMR_KERNEL_FINALIZE = 5,     /* the small reduce/parameter kernels                          */
-  VMR_KERNEL_COUNT = 6
+  VMR_KERNEL_RHO_ELBO = 6,     /* rho update with the ELBO data terms reduced in the same pass */
+  VMR_KERNEL_COUNT = 7
 };
 
 /*

@@ -10,8 +10,8 @@ LIB_PATH = os.path.join(HERE, "libvimure_hip.so")
 
 VMR_OK, VMR_EINVAL, VMR_EHIP, VMR_ENAN, VMR_ESTATE = 0, -1, -2, -3, -4
 STEP_GAMMA, STEP_PHI, STEP_RHO, STEP_NU = 0, 1, 2, 3
-KERNEL_GAMMA_MASK, KERNEL_GAMMA_COUNTS, KERNEL_PHI, KERNEL_RHO, KERNEL_ELBO, KERNEL_FINALIZE = range(6)
-KERNEL_NAMES = ["gamma_mask", "gamma_counts", "phi", "rho", "elbo", "finalize"]
+KERNEL_GAMMA_MASK, KERNEL_GAMMA_COUNTS, KERNEL_PHI, KERNEL_RHO, KERNEL_ELBO, KERNEL_FINALIZE, KERNEL_RHO_ELBO = range(7)
+KERNEL_NAMES = ["gamma_mask", "gamma_counts", "phi", "rho", "elbo", "finalize", "rho_elbo"]
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.c_void_p  # host or device pointer

@@ -48,12 +48,12 @@ struct Geo {
   int Gl;       // workgroups per layer for tile-pair kernels
   int Gm;       // workgroups per layer for the mask kernel
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
+  int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
   int dbg;      // timing experiments only (env VMR_DEBUG): 1 = skip per-report math, 2 = skip the scan
   double eps;
 };
 
 #define NSLOT 8   // accumulation slots per layer for cross-workgroup sums (global f64 atomics)
-#define YT 2      // weight table covers mirror counts 0..YT; larger counts use a fast reciprocal
 
 struct vmr_ctx {
   Geo g;
@@ -161,13 +161,24 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return r;
 }
 
-// 16-bit mask of the non-zero bytes of a 16-byte chunk
-__device__ __forceinline__ unsigned nz_mask4(unsigned d) {
-  unsigned t = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
-  return (((t >> 7) * 0x00204081u) >> 21) & 0xfu;
+// Non-zero-byte flags of a 16-byte chunk, 16 bits spread over a dword: bit 8*b + i (+4 when hi) is set
+// iff byte b of dword i is non-zero.  Two chunks (hi = 0/1) share one dword, four one 64-bit word.
+template <int SH>   // SH = 0 or 4
+__device__ __forceinline__ unsigned nz_flags16(uint4 v) {
+  const unsigned M = 0x7f7f7f7fu;
+  unsigned t0 = ((v.x & M) + M) | v.x, t1 = ((v.y & M) + M) | v.y;
+  unsigned t2 = ((v.z & M) + M) | v.z, t3 = ((v.w & M) + M) | v.w;   // bit 7 of each byte = byte != 0
+  unsigned f = (t0 >> (7 - SH)) & (0x01010101u << SH);
+  f |= (t1 >> (6 - SH)) & (0x02020202u << SH);
+  f |= (t2 >> (5 - SH)) & (0x04040404u << SH);
+  f |= (t3 >> (4 - SH)) & (0x08080808u << SH);
+  return f;
 }
-__device__ __forceinline__ unsigned nz_mask16(uint4 v) {
-  return nz_mask4(v.x) | (nz_mask4(v.y) << 4) | (nz_mask4(v.z) << 8) | (nz_mask4(v.w) << 12);
+// flag position (0..63 in a 64-bit word of four chunks) -> chunk-in-word (0..3) and byte-in-chunk (0..15)
+__device__ __forceinline__ void flag_pos(int bit, int& chunk, int& byte) {
+  const int lo = bit & 31;                       // position inside the dword of a chunk pair
+  chunk = ((bit >> 5) << 1) | ((lo >> 2) & 1);   // dword half, then the +4 flag
+  byte = ((lo & 3) << 2) | (lo >> 3);            // dword i = lo & 3, byte b = lo >> 3  ->  4*i + b
 }
 
 // weight of the theta*lambda part of a report (model.py:685-693): z1 / (z1 + z2), 0-safe
@@ -238,6 +249,43 @@ struct TileStream {
   }
 };
 
+// The same staging for the tile pair's mask rows (64-bit words), 3 words per thread at most.
+struct MaskStream {
+  uint64_t buf[3];
+  unsigned goff[3];
+  unsigned valid, second;
+  __device__ __forceinline__ void init(const Geo& g) {
+    valid = 0; second = 0;
+    const int bb = g.b * g.b;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      int q = threadIdx.x + u * TPB;
+      int tau = q / g.W, w = q - tau * g.W;
+      bool ok = tau < g.nt, sec = tau >= bb;
+      int v = sec ? tau - bb : tau;
+      int p = v >> g.lb, qq = v & (g.b - 1);
+      goff[u] = ok ? (unsigned)((p * g.N + qq) * g.W + w) : 0u;
+      valid |= (ok ? 1u : 0u) << u;
+      second |= (sec ? 1u : 0u) << u;
+    }
+  }
+  __device__ __forceinline__ void fetch(const uint64_t* __restrict__ Rl, const Geo& g, int I0, int J0) {
+    const uint64_t* baseA = Rl + ((size_t)I0 * g.N + J0) * g.W;
+    const uint64_t* baseB = Rl + ((size_t)J0 * g.N + I0) * g.W;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      uint64_t v = 0ull;
+      if ((valid >> u) & 1u) v = (((second >> u) & 1u) ? baseB : baseA)[goff[u]];
+      buf[u] = v;
+    }
+  }
+  __device__ __forceinline__ void store(uint64_t* rw) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if ((valid >> u) & 1u) rw[threadIdx.x + u * TPB] = buf[u];
+  }
+};
+
 // 1/d to ~1 ulp: v_rcp_f64 + two Newton steps (the IEEE divide costs about twice as much)
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
@@ -246,28 +294,30 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
-// Weight table (cache refresh of model.py:685-693 hoisted out of the per-report path):
-//   wt[(y*Mp + m)*K + k] = z1/(z1 + G_nu*y), z1 = G_theta[m] G_lambda[k], for mirror counts y = 0..YT
-// (y = 0 gives 1, or 0 when z1 underflows -- the reference's den==0 -> 1 rule).
+// Weights of the cache refresh (model.py:685-693) without a divide per report:
+//   w1 = z1/(z1 + z2) = 1/(1 + c y),  c[m][k] = G_nu / (G_theta[m] G_lambda[k])  (LDS table, built per launch)
+//   w2 = z2/(z1 + z2) = c y w1.
+// y = 0 gives exactly 1; a z1 that underflows to 0 gives c = inf and w1 = 0 (the reference's den==0 -> 1 rule).
 template <int K>
-__device__ __forceinline__ void build_wt(double* wt, const double* Gth, const double (&Gla)[K], double gnu, int Mp) {
-  for (int q = threadIdx.x; q < (YT + 1) * Mp; q += TPB) {
-    int y = q / Mp, m = q - y * Mp;
+__device__ __forceinline__ void build_ct(double* ct, const double* Gth, const double (&Gla)[K], double gnu, int Mp) {
+  for (int m = threadIdx.x; m < Mp; m += TPB) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) wt[(size_t)q * K + k] = w1_of(Gth[m] * Gla[k], gnu * (double)y);
+    for (int k = 0; k < K; ++k) {
+      double z1 = Gth[m] * Gla[k];
+      ct[(size_t)m * K + k] = (z1 == 0.0) ? (double)INFINITY : gnu / z1;
+    }
   }
 }
 template <int K>
-__device__ __forceinline__ void weights(double (&w)[K], const double* wt, const double* Gth, const double (&Gla)[K],
-                                        double gnu, int Mp, int m, unsigned y) {
-  if (y <= YT) {
-    const double* p = wt + ((size_t)y * Mp + m) * K;
+__device__ __forceinline__ void weights(double (&w)[K], double (&cy)[K], const double* ct, int m, unsigned y) {
+  const double dy = (double)y;
+  const double* p = ct + (size_t)m * K;
 #pragma unroll
-    for (int k = 0; k < K; ++k) w[k] = p[k];
-  } else {   // y > 0 here, so z1 + z2 > 0
-    const double z2 = gnu * (double)y, gt = Gth[m];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { double z1 = gt * Gla[k]; w[k] = z1 * fast_rcp(z1 + z2); }
+  for (int k = 0; k < K; ++k) {
+    const double c = p[k];
+    cy[k] = c * dy;
+    const double r = fast_rcp(1.0 + cy[k]);
+    w[k] = (y == 0) ? ((c < (double)INFINITY) ? 1.0 : 0.0) : r;
   }
 }
 
@@ -280,7 +330,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), lane));
 }
 
-#define HEAVY_ROW 12   // more non-zeros than this in a lane's share of a row -> the whole wave helps
 
 // Visit the non-zero counts of one tie row in LDS.  Lane (tau, s) owns the 16-B chunks {s, s+S, ..}.
 //   phase 1 (no divergence): non-zero-byte masks of up to 12 chunks, 16 bits each, in three words;
@@ -297,11 +346,12 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
   if ((nchunk + S - 1) / S > 12) {   // huge M (b = 1): plain chunk-by-chunk walk
     if (!act) return;
     for (int c = s; c < nchunk; c += S) {
-      unsigned nzm = nz_mask16(*reinterpret_cast<const uint4*>(row + c * 16));
+      unsigned nzm = nz_flags16<0>(*reinterpret_cast<const uint4*>(row + c * 16));
       while (nzm) {
-        int i = __builtin_ctz(nzm);
+        int bit = __builtin_ctz(nzm), ch, by;
         nzm &= nzm - 1;
-        f(c * 16 + i, (unsigned)row[c * 16 + i], own, acc);
+        flag_pos(bit, ch, by);
+        f(c * 16 + by, (unsigned)row[c * 16 + by], own, acc);
       }
     }
     return;
@@ -316,23 +366,29 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
           int c = s + (w * 4 + u) * S;
           int cl = c < nchunk ? c : nchunk - 1;
           uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
-          unsigned m16 = c < nchunk ? nz_mask16(v) : 0u;
-          mk[w] |= (uint64_t)m16 << (16 * u);
+          unsigned f16 = (u & 1) ? nz_flags16<4>(v) : nz_flags16<0>(v);
+          f16 = c < nchunk ? f16 : 0u;
+          mk[w] |= (u < 2) ? (uint64_t)f16 : ((uint64_t)f16 << 32);
         }
       }
     }
   }
   const int cnt = __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]);
-  const bool heavy = cnt > HEAVY_ROW;
+  if (g.dbg & 4) {   // timing experiment: phase 1 only (the impossible count keeps the masks alive)
+    if (cnt == 0x7fffffff) f(0, 0u, own, acc);
+    return;
+  }
+  const bool heavy = cnt > g.heavy;
   if (!heavy) {
     uint64_t cur = mk[0];
     int w = 0;
     for (;;) {
       while (cur == 0 && w < 2) { ++w; cur = (w == 1) ? mk[1] : mk[2]; }
       if (cur == 0) break;
-      int bit = __builtin_ctzll(cur);
+      int bit = __builtin_ctzll(cur), ch, by;
       cur &= cur - 1;
-      int m = (s + (w * 4 + (bit >> 4)) * S) * 16 + (bit & 15);
+      flag_pos(bit, ch, by);
+      int m = (s + (w * 4 + ch) * S) * 16 + by;
       f(m, (unsigned)row[m], own, acc);
     }
   }
@@ -341,7 +397,7 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
   while (hm) {
     const int h = __builtin_ctzll(hm);
     hm &= hm - 1;
-    const Ctx ch = bc(h);
+    const Ctx chx = bc(h);
     const int tau_h = __builtin_amdgcn_readlane(tau, h), s_h = __builtin_amdgcn_readlane(s, h);
     const uint64_t m0 = readlane64(mk[0], h), m1 = readlane64(mk[1], h), m2 = readlane64(mk[2], h);
     const unsigned char* rowh = xt + tau_h * g.stride;
@@ -350,8 +406,10 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
     for (int w = 0; w < 3; ++w) {
       const uint64_t mw = (w == 0) ? m0 : (w == 1) ? m1 : m2;
       if ((mw >> lane) & 1ull) {
-        int m = (s_h + (w * 4 + (lane >> 4)) * S) * 16 + (lane & 15);
-        f(m, (unsigned)rowh[m], ch, tmp);
+        int cq, by;
+        flag_pos(lane, cq, by);
+        int m = (s_h + (w * 4 + cq) * S) * 16 + by;
+        f(m, (unsigned)rowh[m], chx, tmp);
       }
     }
     fin(h, tmp);
@@ -609,21 +667,19 @@ __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* S1 = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
-  double* Gth = S1 + g.Mp;
-  double* red = Gth + g.Mp;
-  double* wt = red + 8;
+  double* red = S1 + g.Mp;
+  double* ct = red + 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
-  for (int m = threadIdx.x; m < g.Mp; m += TPB) { S1[m] = 0.0; Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m]; }
+  for (int m = threadIdx.x; m < g.Mp; m += TPB) S1[m] = 0.0;
   double Gla[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
   const double gnu = a.par[o.sc + SC_G_NU];
   SumK<K> Pk;
   Pk.zero();
-  __syncthreads();
-  if (MUT) build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
+  if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
 
   TileIter it;
   it.init(g, p0);
@@ -632,7 +688,14 @@ __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
   const double* rl = a.rho + (size_t)l * g.N * g.N * K;
   TileStream<PF> ts;
   ts.init(g);
-  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+  double rn[K];   // rho of this lane's tie in the NEXT pair (prefetched like the X chunks)
+  auto fetch_rho = [&]() {
+    int i, j;
+    const bool ok = it.coords(tau, i, j);
+#pragma unroll
+    for (int k = 0; k < K; ++k) rn[k] = ok ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
+  };
+  if (p0 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
     ts.store(xt);
@@ -641,18 +704,18 @@ __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
     TieRho<K> own;
     own.moff = it.mirror(tau) * g.stride;
 #pragma unroll
-    for (int k = 0; k < K; ++k) own.r[k] = act ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
+    for (int k = 0; k < K; ++k) own.r[k] = rn[k];
     __syncthreads();
     it.next();
-    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);   // flies while this pair is scanned
+    if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }   // flies while this pair is scanned
     if (!(g.dbg & 2)) {
       scan_tie(xt, g, tau, s, act, own, Pk,
         [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
           if (g.dbg & 1) { acc.v[0] += (double)x; return; }
           double dx = (double)x, sum = 0.0;
           if (MUT) {
-            double w[K];
-            weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, (unsigned)xt[c.moff + m]);
+            double w[K], cy[K];
+            weights<K>(w, cy, ct, m, (unsigned)xt[c.moff + m]);
 #pragma unroll
             for (int k = 0; k < K; ++k) sum += c.r[k] * w[k];
           } else {
@@ -694,21 +757,18 @@ template <int K, int PF>
 __global__ __launch_bounds__(TPB, 4) void k_phi(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
-  double* Gth = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
-  double* red = Gth + g.Mp;
-  double* wt = red + 8;
+  double* red = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
+  double* ct = red + 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
-  for (int m = threadIdx.x; m < g.Mp; m += TPB) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
   double Gla[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
   const double gnu = a.par[o.sc + SC_G_NU];
   SumK<K> Pk;
   Pk.zero();
-  __syncthreads();
-  build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
+  build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
   TileIter it;
   it.init(g, p0);
   const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
@@ -716,7 +776,14 @@ __global__ __launch_bounds__(TPB, 4) void k_phi(CountArgs a, Geo g) {
   const double* rl = a.rho + (size_t)l * g.N * g.N * K;
   TileStream<PF> ts;
   ts.init(g);
-  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+  double rn[K];   // rho of this lane's tie in the NEXT pair (prefetched like the X chunks)
+  auto fetch_rho = [&]() {
+    int i, j;
+    const bool ok = it.coords(tau, i, j);
+#pragma unroll
+    for (int k = 0; k < K; ++k) rn[k] = ok ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
+  };
+  if (p0 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
     ts.store(xt);
@@ -725,16 +792,16 @@ __global__ __launch_bounds__(TPB, 4) void k_phi(CountArgs a, Geo g) {
     TieRho<K> own;
     own.moff = it.mirror(tau) * g.stride;
 #pragma unroll
-    for (int k = 0; k < K; ++k) own.r[k] = act ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
+    for (int k = 0; k < K; ++k) own.r[k] = rn[k];
     __syncthreads();
     it.next();
-    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+    if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
     if (!(g.dbg & 2)) {
       scan_tie(xt, g, tau, s, act, own, Pk,
         [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
           if (g.dbg & 1) { acc.v[0] += (double)x; return; }
-          double dx = (double)x, w[K];
-          weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, (unsigned)xt[c.moff + m]);
+          double dx = (double)x, w[K], cy[K];
+          weights<K>(w, cy, ct, m, (unsigned)xt[c.moff + m]);
 #pragma unroll
           for (int k = 0; k < K; ++k) acc.v[k] += dx * c.r[k] * w[k];
         },
@@ -776,7 +843,7 @@ struct TieMirror { int moff; };   // rho update: a report only needs the mirrore
 template <int K>
 struct TieElbo {                  // ELBO: exp(rho) of the tie, its mask row and the mirror's
   double er[K];
-  int moff, roff, rmoff, mtau;
+  int moff, roff, rmoff;
 };
 template <int K>
 struct SumUV {
@@ -786,9 +853,10 @@ struct SumUV {
     for (int k = 0; k < K; ++k) { U[k] = 0.0; V[k] = 0.0; }
   }
 };
-struct Sum1 {
+struct SumEQ {   // ELBO scan: log terms (any lane may keep them) and the mirror's masked count (per tie)
   double v;
-  __device__ __forceinline__ void zero() { v = 0.0; }
+  unsigned q;
+  __device__ __forceinline__ void zero() { v = 0.0; q = 0u; }
 };
 
 template <int K, bool MUT, bool UPDATE, bool ELBO, int PF>
@@ -802,7 +870,7 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
   double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* Gth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
-  double* wt = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)(YT + 1) * g.Mp * K * 8 : 0;
+  double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
   unsigned* qs = reinterpret_cast<unsigned*>(smem + off);
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
@@ -833,15 +901,14 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];
   const double eps = g.eps;
   double nu_acc = 0.0, e_lin = 0.0, e_q = 0.0;
-  Sum1 e_log;
-  e_log.zero();
+  double e_log = 0.0;
   __syncthreads();
   for (int w = threadIdx.x; w < g.W; w += TPB) {
     double v = 0.0;
     for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
     wsum[w] = v;
   }
-  if (MUT) build_wt<K>(wt, Gth, Gla, gnu, g.Mp);
+  if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
 
   TileIter it;
   it.init(g, p0);
@@ -853,29 +920,34 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
   const double* lpl = a.logpr + (size_t)l * T * K;
   TileStream<PF> ts;
   ts.init(g);
-  if (p0 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+  MaskStream ms;
+  ms.init(g);
+  double lpn[K], rn[K];   // log prior (and rho, ELBO-only) of this lane's tie in the NEXT pair
+  auto fetch_tie = [&]() {
+    int i, j;
+    const bool ok = it.coords(tau, i, j);
+    const size_t t_ = ok ? ((size_t)i * g.N + j) : 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      lpn[k] = ok ? lpl[t_ * K + k] : 0.0;
+      rn[k] = (!UPDATE && ok) ? rl[t_ * K + k] : 0.0;
+    }
+  };
+  if (p0 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); ms.fetch(Rl, g, it.I * g.b, it.J * g.b); fetch_tie(); }
   __syncthreads();
   for (long long p = p0; p < p1; ++p) {
     ts.store(xt);
-    const int nt_cur = it.diag() ? it.bb : 2 * it.bb;
-    for (int q = threadIdx.x; q < nt_cur * g.W; q += TPB) {
-      int tq = q / g.W, w = q - tq * g.W, i2, j2;
-      rw[q] = it.coords(tq, i2, j2) ? Rl[((size_t)i2 * g.N + j2) * g.W + w] : 0ull;
-    }
-    if (ELBO) { for (int q = threadIdx.x; q < g.nt; q += TPB) qs[q] = 0u; }
+    ms.store(rw);
     int i, j;
     const bool act = it.coords(tau, i, j);
     const size_t tg = act ? ((size_t)i * g.N + j) : 0;
     const int mtau = it.mirror(tau);
     double lp[K], r[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      lp[k] = act ? lpl[tg * K + k] : 0.0;
-      r[k] = (!UPDATE && act) ? rl[tg * K + k] : 0.0;
-    }
+    for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
     __syncthreads();
     it.next();
-    if (p + 1 < p1) ts.fetch(Xl, g, it.I * g.b, it.J * g.b);
+    if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); ms.fetch(Rl, g, it.I * g.b, it.J * g.b); fetch_tie(); }
     double Tt = 0.0;
     if (act) {
       // T = sum_m R E[theta_m] (model.py:766-792): whole-word shortcut, else nibble look-ups
@@ -899,13 +971,12 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
             const double dx = (double)x, lt = lth[m];
             if (MUT) {
               const unsigned y = xt[c.moff + m];
-              double w[K];
-              weights<K>(w, wt, Gth, Gla, gnu, g.Mp, m, y);
+              double w[K], cy[K];
+              weights<K>(w, cy, ct, m, y);
 #pragma unroll
-              for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * (dx * w[k]);
-              if (y != 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc.V[k] += dx * (1.0 - w[k]);   // x w2_k, model.py:694-696
+              for (int k = 0; k < K; ++k) {
+                acc.U[k] += (lt + lla[k]) * (dx * w[k]);
+                acc.V[k] += (y != 0) ? dx * (cy[k] * w[k]) : 0.0;   // x w2_k, model.py:694-696
               }
             } else {
 #pragma unroll
@@ -951,9 +1022,11 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
       TieElbo<K> own;
 #pragma unroll
       for (int k = 0; k < K; ++k) own.er[k] = exp(r[k]);   // exp(rho), model.py:971
-      own.moff = mtau * g.stride; own.roff = tau * g.W; own.rmoff = mtau * g.W; own.mtau = mtau;
-      scan_tie(xt, g, tau, s, act, own, e_log,
-        [&](int m, unsigned x, const TieElbo<K>& c, Sum1& acc) {
+      own.moff = mtau * g.stride; own.roff = tau * g.W; own.rmoff = mtau * g.W;
+      SumEQ eq;
+      eq.zero();
+      scan_tie(xt, g, tau, s, act, own, eq,
+        [&](int m, unsigned x, const TieElbo<K>& c, SumEQ& acc) {
           const double dx = (double)x;
           const unsigned y = MUT ? (unsigned)xt[c.moff + m] : 0u;
           const bool in_r = (rw[c.roff + (m >> 6)] >> (m & 63)) & 1ull;
@@ -964,17 +1037,26 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
             for (int k = 0; k < K; ++k) inner += c.er[k] * (Gth[m] * Gla[k] + z2);
           }
           acc.v += dx * log(inner + eps);
-          if (MUT && ((rw[c.rmoff + (m >> 6)] >> (m & 63)) & 1ull)) atomicAdd(&qs[c.mtau], x);   // R[mirror] X^T[mirror]
+          if (MUT && ((rw[c.rmoff + (m >> 6)] >> (m & 63)) & 1ull)) acc.q += x;   // R[mirror] X^T[mirror]
         },
         [&](int h) {
           TieElbo<K> c;
 #pragma unroll
           for (int k = 0; k < K; ++k) c.er[k] = readlane_f64(own.er[k], h);
           c.moff = __builtin_amdgcn_readlane(own.moff, h); c.roff = __builtin_amdgcn_readlane(own.roff, h);
-          c.rmoff = __builtin_amdgcn_readlane(own.rmoff, h); c.mtau = __builtin_amdgcn_readlane(own.mtau, h);
+          c.rmoff = __builtin_amdgcn_readlane(own.rmoff, h);
           return c;
         },
-        [&](int, const Sum1& t) { e_log.v += t.v; });
+        [&](int h, const SumEQ& t) {
+          eq.v += t.v;
+          unsigned tq = t.q;
+#pragma unroll
+          for (int o2 = 32; o2 > 0; o2 >>= 1) tq += __shfl_xor(tq, o2, 64);
+          if (lane == h) eq.q += tq;
+        });
+      e_log += eq.v;
+      const unsigned qtot = group_sum_u(eq.q, g.S);
+      if (act && s == 0) qs[mtau] = qtot;   // Q of the MIRROR tie: sum_m R[mirror,m] X[this,m]
       __syncthreads();
       if (act && s == 0) {
         double sr = 0.0, se = 0.0, ent = 0.0;
@@ -991,7 +1073,7 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
   }
   double v0 = block_sum(nu_acc, red);
   double v1 = block_sum(e_lin, red);
-  double v2 = block_sum(e_log.v, red);
+  double v2 = block_sum(e_log, red);
   double v3 = block_sum(e_q, red);
   if (threadIdx.x == 0) {
     double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
@@ -1125,12 +1207,12 @@ static int fail(vmr_handle h, int code, const char* msg) {
   return code;
 }
 
-static size_t shmem_wt(const Geo& g) { return g.mut ? (size_t)(YT + 1) * g.Mp * g.K * 8 : 0; }
-static size_t shmem_counts(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 16 + 64 + shmem_wt(g); }
-static size_t shmem_phi(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + shmem_wt(g); }
+static size_t shmem_ct(const Geo& g) { return g.mut ? (size_t)g.Mp * g.K * 8 : 0; }
+static size_t shmem_counts(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + shmem_ct(g); }
+static size_t shmem_phi(const Geo& g) { return (size_t)g.nt * g.stride + 64 + shmem_ct(g); }
 static size_t shmem_rho(const Geo& g) {
   return (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.W * 8 +
-         (size_t)g.Mp * 16 + 64 + shmem_wt(g) + (size_t)g.nt * 4 + 16;
+         (size_t)g.Mp * 16 + 64 + shmem_ct(g) + (size_t)g.nt * 4 + 16;
 }
 
 struct Prof {
@@ -1254,7 +1336,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (h->slotR_dirty) HIPCHK(h, hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
   h->slotR_dirty = (mode == 0 && !commit_nu);
   {
-    Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : VMR_KERNEL_RHO);
+    Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
   DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_rho<KK, MUT_, UPD_, ELB_, PP>, sm, &a.Gl))) return rc; \
               hipLaunchKernelGGL((k_rho<KK, MUT_, UPD_, ELB_, PP>), dim3(g.L * a.Gl), blk, sm, h->stream, a, g))
@@ -1296,6 +1378,8 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.Gm = (int)gm;
   int need = (g.nt * g.nchunk + TPB - 1) / TPB;
   g.pf = need <= 4 ? 4 : need <= 8 ? 8 : 12;
+  const char* hv = getenv("VMR_HEAVY");
+  g.heavy = hv ? atoi(hv) : 12;
   const char* dbg = getenv("VMR_DEBUG");
   g.dbg = dbg ? atoi(dbg) : 0;
   return VMR_OK;
@@ -1335,7 +1419,8 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   const size_t slack = (size_t)g.b * N + g.b;   // tile streams may read (never use) rows past the last tie
   CCHK(hipMalloc(&h->X, (rows + slack) * g.Mp));
   CCHK(hipMemsetAsync(h->X + rows * g.Mp, 0, slack * g.Mp, h->stream));
-  CCHK(hipMalloc(&h->Rb, rows * g.W * 8));
+  CCHK(hipMalloc(&h->Rb, (rows + slack) * g.W * 8));
+  CCHK(hipMemsetAsync(h->Rb + rows * g.W, 0, slack * g.W * 8, h->stream));
   CCHK(hipMalloc(&h->cov, rows));
   CCHK(hipMalloc(&h->sumx, 8));
   CCHK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
@@ -1597,6 +1682,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
     case VMR_KERNEL_PHI: *bytes = SX + Srho; break;
     case VMR_KERNEL_RHO: *bytes = SX + SR + 2.0 * Srho; break;
     case VMR_KERNEL_ELBO: *bytes = SX + SR + 2.0 * Srho; break;
+    case VMR_KERNEL_RHO_ELBO: *bytes = SX + SR + 2.0 * Srho; break;
     default: *bytes = 0.0; break;
   }
   return VMR_OK;
