@@ -1,0 +1,86 @@
+"""Host logic of vimure_amd.VimureModel that runs before the engine: argument validation with the
+reference's messages (model.py:79-325), RandomState-exact initial draws (model.py:458-605)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import vimure_oracle as vo
+from tests.golden_util import case_config, load_case
+from vimure_amd.model import VimureModel
+
+
+def small():
+    d = load_case("A_ones_mut")
+    return d["X"], d["R"]
+
+
+def test_undirected_overrides_mutuality_with_warning():
+    with pytest.warns(UserWarning, match="Overriding mutuality"):
+        m = VimureModel(undirected=True, mutuality=True)
+    assert m.mutuality is False
+
+
+def test_undirected_needs_symmetric_x():
+    X, R = small()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel(undirected=True)
+    with pytest.raises(ValueError, match="has to be symmetric"):
+        m.fit(X, R=R, K=2)
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(theta_prior=[0.1, 0.1]), "theta_prior must be a 2D tuple!"),
+    (dict(lambda_prior=(1.0,)), "lambda_prior must be a 2D tuple!"),
+    (dict(eta_prior=0.5), "eta_prior must be a 2D tuple!"),
+    (dict(rho_prior=np.zeros((2, 3, 3))), "rho_prior has to have shape"),
+    (dict(alpha_lambda=np.ones((3, 3)), beta_lambda=np.ones((1, 2))), "alpha_lambda matrix is not valid"),
+    (dict(alpha_theta=np.ones((1, 3)), beta_theta=np.ones((1, 8))), "alpha_theta matrix is not valid"),
+])
+def test_bad_priors_raise_reference_messages(kw, msg):
+    X, R = small()
+    with pytest.raises(ValueError, match=msg):
+        VimureModel().fit(X, R=R, K=2, **kw)
+
+
+def test_bad_mask_shape():
+    X, R = small()
+    with pytest.raises(ValueError, match="Dimensions of reporter mask"):
+        VimureModel().fit(X, R=R[:, :, :, :-1], K=2)
+
+
+def test_counts_above_255_rejected():
+    X, R = small()
+    with pytest.raises(ValueError, match="255"):
+        VimureModel().fit(X.astype(np.int64) * 300, R=R, K=2)
+
+
+def test_missing_k_and_r_warn_then_engine_refuses_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    X, R = small()
+    with pytest.warns(UserWarning) as rec:
+        with pytest.raises(Exception):      # validation passes, the engine then needs a HIP device
+            VimureModel().fit(X, seed=1)
+    msgs = " | ".join(str(w.message) for w in rec)
+    assert "Parameter K was None. Defaulting to" in msgs and "Reporters Mask was not informed" in msgs
+
+
+@pytest.mark.parametrize("name", ["A_ones_mut", "C_ones_nomut", "F_rho_prior", "E_undirected"])
+def test_initial_draws_are_bit_exact(name):
+    """The host class draws pr_rho / gamma / phi / nu exactly as the reference does for a seed."""
+    d = load_case(name)
+    K, mut, und, seed, priors, fitargs, rho_prior = case_config(d)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel(mutuality=bool(d["mutuality"]), undirected=und)
+        m._check_fit_params(d["X"], (10.0, 10.0), (0.1, 0.1), (0.5, 1.0), rho_prior, seed, R=d["R"], K=K, **priors)
+    cov = (d["R"].any(axis=3) & (d["X"] != 0).any(axis=3)).astype(np.uint8)
+    pr = m._draw_pr_rho(cov, 0.0)
+    m._draw_gammas(float(d["X"].sum()))
+    assert np.array_equal(pr, d["init_pr_rho"])
+    for n in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte"):
+        assert np.array_equal(np.broadcast_to(getattr(m, n), d["init_" + n].shape), d["init_" + n]), n
+    assert m.nu_shp == float(d["init_nu_shp"]) and m.nu_rte == float(d["init_nu_rte"])
