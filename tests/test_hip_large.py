@@ -1,0 +1,99 @@
+"""GPU parity at sizes the small golden cases do not reach (M = 200 rows, 13 chunks per row, heavy
+true-tie rows, several tile pairs per workgroup, ragged edge tiles): HIP engine vs the plain-C oracle
+on the same seeded synthetic network after a few sweeps, plus size-independent properties."""
+import numpy as np
+import pytest
+
+from oracle import cavi_ref
+from oracle import vimure_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2):
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    net = standard_sbm(N=N, M=M, L=L, K=K, avg_degree=5.0, eta=eta, seed=0)
+    g = np.random.RandomState(7)
+    if mask == "ones":
+        R = None
+    elif mask == "random":
+        R = (g.rand(L, N, N, M) < 0.7).astype(np.uint8)
+    X = net.X
+    pr = vo.make_priors(L, M, K)
+    pb_cov = (np.ones((L, N, N), bool) if R is None else R.any(axis=3)) & (X != 0).any(axis=3)
+    prng = np.random.RandomState(seed)
+    pr_rho = 1.0 + 0.01 * prng.rand(L, N, N, K)
+    pr_rho /= pr_rho.sum(axis=-1)[..., None]
+    onehot = np.zeros(K); onehot[0] = 1.0
+    pr_rho[~pb_cov] = onehot
+    gs = 0.1 * prng.random_sample((L, M)) + 0.1
+    ps = 10.0 * prng.random_sample((L, K)) + 10.0
+    gr = 0.1 * prng.random_sample((L, M)) + 0.1
+    prt = 10.0 * prng.random_sample((L, K)) + 10.0
+    nu_s, nu_r = (0.5 * prng.random_sample(1)[0] + 0.5, 1.0 + float(X.sum())) if mutuality else (1e-6, 1.0)
+    c = cavi_ref.CRef(X, R, K, mutuality, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), gs, gr, ps, prt, nu_s, nu_r, pr_rho)
+    eng = CaviEngine(X, R, K=K, mutuality=mutuality)
+    s, cov = eng.data_stats()
+    assert s == float(X.sum()) and np.array_equal(cov.astype(bool), pb_cov)
+    eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+    eng.set_state(gs, gr, ps, prt, nu_s, nu_r, pr_rho)
+    e_gpu = None
+    for it in range(sweeps):
+        c.cavi_step()
+        e_gpu = eng.step(1, want_elbo=True)
+    e_cpu = c.elbo()
+    st = eng.get_state()
+    assert abs(e_gpu - e_cpu) <= 1e-9 * max(1.0, abs(e_cpu)), (e_gpu, e_cpu)
+    assert abs(eng.elbo() - e_cpu) <= 1e-9 * max(1.0, abs(e_cpu))
+    np.testing.assert_allclose(st["rho"], c.rho, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(st["gamma_shp"], c.gamma_shp, rtol=1e-9)
+    np.testing.assert_allclose(st["gamma_rte"], c.gamma_rte, rtol=1e-9)
+    np.testing.assert_allclose(st["phi_shp"], c.phi_shp, rtol=1e-9)
+    np.testing.assert_allclose(st["phi_rte"], c.phi_rte, rtol=1e-9)
+    np.testing.assert_allclose(st["nu_shp"], c.nu_shp, rtol=1e-9)
+    # properties that hold at any size: rho rows are distributions (or all-zero after underflow), finite
+    rs = st["rho"].sum(axis=-1)
+    assert np.all(np.isfinite(st["rho"])) and np.all((np.abs(rs - 1.0) < 1e-12) | (rs == 0.0))
+    eng.close()
+
+
+def test_m200_mutuality_all_ones_mask():
+    _run(L=2, N=333, M=200, K=2, eta=0.5, mutuality=True, mask="ones")     # ragged tiles: 333 = 41*8 + 5
+
+
+def test_m200_random_mask_k3():
+    _run(L=1, N=250, M=200, K=3, eta=0.4, mutuality=True, mask="random")
+
+
+def test_m1000_tile_edge4_no_mutuality():
+    _run(L=1, N=90, M=1000, K=2, eta=0.0, mutuality=False, mask="random", sweeps=2)   # b = 4, 16 mask words
+
+
+def test_m50_small_rows():
+    _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones")
+
+
+def test_subnormal_normaliser_is_divided_not_inverted():
+    """A tie whose unnormalised rho sums to a subnormal number must still normalise (rho/sum, model.py:811);
+    1/sum would overflow.  Force it with a tie reported by everybody under a tiny lambda prior mass."""
+    from vimure_amd import CaviEngine
+    L, N, M, K = 1, 16, 200, 2
+    X = np.zeros((L, N, N, M), np.uint8)
+    X[0, 1, 2, :] = 3
+    X[0, 2, 1, :] = 1
+    pr_rho = np.full((L, N, N, K), 0.5)
+    gs, gr = np.full((L, M), 0.2), np.full((L, M), 5.0)
+    ps, prt = np.full((L, K), 1.0), np.full((L, K), 40.0)
+    pri = (0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+    c = cavi_ref.CRef(X, None, K, True, pri, gs, gr, ps, prt, 0.7, 1.0 + float(X.sum()), pr_rho)
+    eng = CaviEngine(X, None, K=K, mutuality=True)
+    eng.set_priors(*pri)
+    eng.set_state(gs, gr, ps, prt, 0.7, 1.0 + float(X.sum()), pr_rho)
+    from vimure_amd import _lib
+    eng.sub_step(_lib.STEP_RHO)
+    c.update_rho()
+    g = eng.get_state()["rho"]
+    assert np.all(np.isfinite(g))
+    np.testing.assert_allclose(g, c.rho, rtol=1e-9, atol=1e-300)
+    eng.close()

@@ -312,6 +312,16 @@ template <int K>
 __device__ __forceinline__ void weights(double (&w)[K], double (&cy)[K], const double* ct, int m, unsigned y) {
   const double dy = (double)y;
   const double* p = ct + (size_t)m * K;
+  if (K == 2) {   // one reciprocal for both categories: 1/a0 = a1/(a0 a1)
+    const double c0 = p[0], c1 = p[1];
+    if (c0 < (double)INFINITY && c1 < (double)INFINITY) {
+      cy[0] = c0 * dy; cy[1] = c1 * dy;
+      const double a0 = 1.0 + cy[0], a1 = 1.0 + cy[1];
+      const double r = fast_rcp(a0 * a1);
+      w[0] = a1 * r; w[1] = a0 * r;   // y = 0: a0 = a1 = 1 and r = 1 exactly
+      return;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double c = p[k];
@@ -356,60 +366,66 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
     }
     return;
   }
-  uint64_t mk[3] = {0, 0, 0};
+  // phase 1: one flag per DWORD of the lane's (up to 12) chunks: bit 4*j + i <-> dword i of chunk s + j*S
+  unsigned lo = 0, hi = 0;   // chunks 0..7 / 8..11
   if (act) {
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if ((w * 4 + u) * S < nchunk) {   // wave-uniform
-          int c = s + (w * 4 + u) * S;
-          int cl = c < nchunk ? c : nchunk - 1;
-          uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
-          unsigned f16 = (u & 1) ? nz_flags16<4>(v) : nz_flags16<0>(v);
-          f16 = c < nchunk ? f16 : 0u;
-          mk[w] |= (u < 2) ? (uint64_t)f16 : ((uint64_t)f16 << 32);
-        }
+    for (int j = 0; j < 12; ++j) {
+      if (j * S < nchunk) {   // wave-uniform
+        const int c = s + j * S;
+        const int cl = c < nchunk ? c : nchunk - 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
+        unsigned f4 = min(v.x, 1u) | (min(v.y, 1u) << 1) | (min(v.z, 1u) << 2) | (min(v.w, 1u) << 3);
+        f4 = c < nchunk ? f4 : 0u;
+        if (j < 8) lo |= f4 << (4 * j); else hi |= f4 << (4 * (j - 8));
       }
     }
   }
-  const int cnt = __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]);
-  if (g.dbg & 4) {   // timing experiment: phase 1 only (the impossible count keeps the masks alive)
+  const int cnt = __popc(lo) + __popc(hi);   // non-zero dwords of the share
+  if (g.dbg & 4) {   // timing experiment: phase 1 only (the impossible count keeps the flags alive)
     if (cnt == 0x7fffffff) f(0, 0u, own, acc);
     return;
   }
   const bool heavy = cnt > g.heavy;
   if (!heavy) {
-    uint64_t cur = mk[0];
-    int w = 0;
+    // phase 2: one non-zero count per trip; a new dword is fetched when the current one is used up
+    unsigned d = 0;
+    int off = 0;
     for (;;) {
-      while (cur == 0 && w < 2) { ++w; cur = (w == 1) ? mk[1] : mk[2]; }
-      if (cur == 0) break;
-      int bit = __builtin_ctzll(cur), ch, by;
-      cur &= cur - 1;
-      flag_pos(bit, ch, by);
-      int m = (s + (w * 4 + ch) * S) * 16 + by;
-      f(m, (unsigned)row[m], own, acc);
+      if (d == 0) {
+        int p;
+        if (lo) { p = __builtin_ctz(lo); lo &= lo - 1; }
+        else if (hi) { p = 32 + __builtin_ctz(hi); hi &= hi - 1; }
+        else break;
+        off = (s + (p >> 2) * S) * 16 + (p & 3) * 4;
+        d = *reinterpret_cast<const unsigned*>(row + off);
+      }
+      const int sh = __builtin_ctz(d) & ~7;
+      const unsigned x = (d >> sh) & 0xffu;
+      d &= ~(0xffu << sh);
+      f(off + (sh >> 3), x, own, acc);
     }
   }
   uint64_t hm = __ballot(heavy);
   const int lane = threadIdx.x & 63;
-  while (hm) {
+  while (hm) {   // heavy shares: lane p < 48 takes dword p of the share
     const int h = __builtin_ctzll(hm);
     hm &= hm - 1;
     const Ctx chx = bc(h);
     const int tau_h = __builtin_amdgcn_readlane(tau, h), s_h = __builtin_amdgcn_readlane(s, h);
-    const uint64_t m0 = readlane64(mk[0], h), m1 = readlane64(mk[1], h), m2 = readlane64(mk[2], h);
+    const unsigned lo_h = __builtin_amdgcn_readlane((int)lo, h), hi_h = __builtin_amdgcn_readlane((int)hi, h);
     const unsigned char* rowh = xt + tau_h * g.stride;
     Acc tmp;
     tmp.zero();
-    for (int w = 0; w < 3; ++w) {
-      const uint64_t mw = (w == 0) ? m0 : (w == 1) ? m1 : m2;
-      if ((mw >> lane) & 1ull) {
-        int cq, by;
-        flag_pos(lane, cq, by);
-        int m = (s_h + (w * 4 + cq) * S) * 16 + by;
-        f(m, (unsigned)rowh[m], chx, tmp);
+    const bool mine = lane < 32 ? ((lo_h >> lane) & 1u) : (lane < 48 ? ((hi_h >> (lane - 32)) & 1u) : false);
+    if (mine) {
+      const int off = (s_h + (lane >> 2) * S) * 16 + (lane & 3) * 4;
+      unsigned d = *reinterpret_cast<const unsigned*>(rowh + off);
+      while (d) {
+        const int sh = __builtin_ctz(d) & ~7;
+        const unsigned x = (d >> sh) & 0xffu;
+        d &= ~(0xffu << sh);
+        f(off + (sh >> 3), x, chx, tmp);
       }
     }
     fin(h, tmp);
@@ -1003,7 +1019,7 @@ __global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
         r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
         sum += r[k];
       }
-      if (sum > 0.0) {   // model.py:808-811
+      if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] /= sum;
       }
@@ -1379,7 +1395,7 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   int need = (g.nt * g.nchunk + TPB - 1) / TPB;
   g.pf = need <= 4 ? 4 : need <= 8 ? 8 : 12;
   const char* hv = getenv("VMR_HEAVY");
-  g.heavy = hv ? atoi(hv) : 12;
+  g.heavy = hv ? atoi(hv) : 8;   // in non-zero DWORDS of the share
   const char* dbg = getenv("VMR_DEBUG");
   g.dbg = dbg ? atoi(dbg) : 0;
   return VMR_OK;
