@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvimure_hip.so")
+LIB_PATH = os.environ.get("VMR_LIB", os.path.join(HERE, "libvimure_hip.so"))  # VMR_LIB: A/B builds of the engine
 
 VMR_OK, VMR_EINVAL, VMR_EHIP, VMR_ENAN, VMR_ESTATE = 0, -1, -2, -3, -4
 STEP_GAMMA, STEP_PHI, STEP_RHO, STEP_NU = 0, 1, 2, 3

@@ -29,6 +29,15 @@
 
 #define VMR_VERSION "vimure_hip 0.1 (gfx950)"
 #define TPB 256
+#ifndef VMR_LB_COUNTS
+#define VMR_LB_COUNTS 4   // resident workgroups per CU the gamma/phi sweeps are compiled for
+#endif
+#ifndef VMR_LB_RHO
+#define VMR_LB_RHO 3
+#endif
+#ifndef VMR_NR_STEPS
+#define VMR_NR_STEPS 1   // v_rcp_f64 is good to 4.6e-8; one step gives 2e-15, two are exact (tools/rcp_accuracy.hip)
+#endif
 #define KMAX 8
 
 // ------------------------------------------------------------------------------------------
@@ -59,6 +68,8 @@ struct vmr_ctx {
   Geo g;
   int device;
   hipStream_t stream;
+  hipStream_t stream2 = nullptr;     // the mask half of the gamma update runs beside the counts half
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   // data
   uint8_t* X = nullptr;        // [L][N*N][Mp]
@@ -286,11 +297,11 @@ struct MaskStream {
   }
 };
 
-// 1/d to ~1 ulp: v_rcp_f64 + two Newton steps (the IEEE divide costs about twice as much)
+// 1/d: v_rcp_f64 (4.6e-8) + VMR_NR_STEPS Newton steps (one: 2e-15, two: exact); the IEEE divide costs ~2x
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
+#pragma unroll
+  for (int i = 0; i < VMR_NR_STEPS; ++i) r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
 
@@ -679,7 +690,7 @@ struct TileIter {
 };
 
 template <int K, bool MUT, int PF>
-__global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_gamma_counts(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* S1 = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
@@ -770,7 +781,7 @@ __global__ __launch_bounds__(TPB, 4) void k_gamma_counts(CountArgs a, Geo g) {
 // NEW E[log theta] -- the cache refresh of model.py:647 sits between the two updates.
 // ------------------------------------------------------------------------------------------
 template <int K, int PF>
-__global__ __launch_bounds__(TPB, 4) void k_phi(CountArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* red = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
@@ -876,7 +887,7 @@ struct SumEQ {   // ELBO scan: log terms (any lane may keep them) and the mirror
 };
 
 template <int K, bool MUT, bool UPDATE, bool ELBO, int PF>
-__global__ __launch_bounds__(TPB, 3) void k_rho(RhoArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   size_t off = (size_t)g.nt * g.stride;
@@ -1232,12 +1243,12 @@ static size_t shmem_rho(const Geo& g) {
 }
 
 struct Prof {
-  vmr_ctx* h; int cls; hipEvent_t a = nullptr, b = nullptr;
-  Prof(vmr_ctx* h_, int c) : h(h_), cls(c) {
-    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); }
+  vmr_ctx* h; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  Prof(vmr_ctx* h_, int c, hipStream_t st_ = nullptr) : h(h_), cls(c), st(st_ ? st_ : h_->stream) {
+    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
   }
   ~Prof() {
-    if (h->prof) { (void)hipEventRecord(b, h->stream); h->evs.push_back({cls, a, b}); }
+    if (h->prof) { (void)hipEventRecord(b, st); h->evs.push_back({cls, a, b}); }
   }
 };
 
@@ -1290,16 +1301,21 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
 
 static int launch_gamma(vmr_ctx* h) {
   const Geo& g = h->g;
+  // fork: the mask half (memory/latency-bound, few VALU ops) overlaps the counts half (VALU-bound)
+  hipStream_t ms = h->stream2;
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(ms, h->ev_fork, 0));
   {
-    Prof p(h, VMR_KERNEL_GAMMA_MASK);
+    Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
     switch (g.W >= 4 ? 4 : g.W) {
-      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
-      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
-      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
-      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, h->stream, h->Rb, h->rho, h->slotA, g)); break;
+      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
+      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
+      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
+      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
     }
   }
+  HIPCHK(h, hipEventRecord(h->ev_join, ms));
   {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     CountArgs a{h->X, h->rho, h->par, h->slotS1, h->slotP, 1};
@@ -1313,6 +1329,7 @@ static int launch_gamma(vmr_ctx* h) {
                   hipLaunchKernelGGL((k_gamma_counts<KK, false, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
     }
   }
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));   // join
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->slotS1, h->slotA, h->slotP, g);
@@ -1429,6 +1446,9 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
 #define CCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); vmr_destroy(h); return VMR_EHIP; } } while (0)
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   const size_t rows = (size_t)L * N * N;
   const size_t raw = rows * M;
   h->ncu = prop.multiProcessorCount;
@@ -1481,6 +1501,9 @@ void vmr_destroy(vmr_handle h) {
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotS1, h->slotA, h->slotP, h->slotR, h->elbo_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
