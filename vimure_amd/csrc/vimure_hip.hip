@@ -85,6 +85,7 @@ struct vmr_ctx {
   double* elbo_dev = nullptr;  // [0] elbo
   bool have_priors = false, have_state = false;
   bool slotR_dirty = false;
+  bool serial = false;
   int ncu = 256;
   std::vector<std::pair<const void*, int>> occ;   // kernel -> resident workgroups per CU   // a rho sub-step left an unconsumed nu partial in slotR
   // profiling
@@ -352,33 +353,47 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 
-// Visit the non-zero counts of one tie row in LDS.  Lane (tau, s) owns the 16-B chunks {s, s+S, ..}.
-//   phase 1 (no divergence): non-zero-byte masks of up to 12 chunks, 16 bits each, in three words;
-//   light shares: the lane walks its own set bits -- f(m, x, own, acc);
-//   heavy shares (a true tie is reported by most reporters: ~100 non-zeros in one row while the
-//   typical row has 2-5): the share's masks and context are broadcast with v_readlane and all 64
-//   lanes take one bit position each -- f(m, x, bc(h), tmp) -- then fin(h, tmp) hands tmp back.
+// Per-tie accumulators a report may feed (reduced over the wave when a heavy share is processed cooperatively)
+struct NoAcc {
+  __device__ __forceinline__ void zero() {}
+  __device__ __forceinline__ void wave_reduce() {}
+};
+
+#define QCAP 6   // a lane queues at most this many non-zero dwords; larger shares are "heavy"
+
+// Visit the non-zero counts of the tile rows owned by one wave.  Lane (tau, s) owns the 16-B chunks
+// {s, s+S, ..} of row tau.
+//   phase 1 (no divergence): one flag per DWORD of the lane's chunks (v_min_u32 + v_lshl_or);
+//   phase 2: the flags of all 64 lanes are compacted into a wave-local LDS queue of (lane, dword) entries
+//            (ballot/mbcnt prefix sums), so that the per-report arithmetic runs with every lane busy --
+//            without it a wave runs max-over-lanes(non-zeros) trips at ~30 % lane utilisation;
+//   heavy shares (a true tie is reported by most reporters: ~100 non-zeros in a row whose neighbours have
+//            2-5): not queued; all lanes take one dword each, sums come back through a wave reduction.
+// f(tau_e, m, x, acc) handles one report of tie slot tau_e; commit(tau_e, acc) adds acc to that tie's sums.
 // Must be called by every lane of the wave (act = false for lanes without a tie).
-template <class Ctx, class Acc, class F, class BC, class FIN>
-__device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, int tau, int s, bool act, const Ctx& own,
-                                         Acc& acc, F&& f, BC&& bc, FIN&& fin) {
+template <class TieAcc, class F, class C>
+__device__ __forceinline__ void scan_tile(const unsigned char* xt, const Geo& g, int tau, int s, bool act,
+                                          unsigned short* wq, F&& f, C&& commit) {
   const int S = g.S, nchunk = g.nchunk;
   const unsigned char* row = xt + tau * g.stride;
   if ((nchunk + S - 1) / S > 12) {   // huge M (b = 1): plain chunk-by-chunk walk
     if (!act) return;
+    TieAcc a;
+    a.zero();
     for (int c = s; c < nchunk; c += S) {
       unsigned nzm = nz_flags16<0>(*reinterpret_cast<const uint4*>(row + c * 16));
       while (nzm) {
         int bit = __builtin_ctz(nzm), ch, by;
         nzm &= nzm - 1;
         flag_pos(bit, ch, by);
-        f(c * 16 + by, (unsigned)row[c * 16 + by], own, acc);
+        f(tau, c * 16 + by, (unsigned)row[c * 16 + by], a);
       }
     }
+    commit(tau, a);
     return;
   }
-  // phase 1: one flag per DWORD of the lane's (up to 12) chunks: bit 4*j + i <-> dword i of chunk s + j*S
-  unsigned lo = 0, hi = 0;   // chunks 0..7 / 8..11
+  // phase 1: bit 4*j + i <-> dword i of chunk s + j*S   (lo: chunks 0..7, hi: chunks 8..11)
+  unsigned lo = 0, hi = 0;
   if (act) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
@@ -394,52 +409,74 @@ __device__ __forceinline__ void scan_tie(const unsigned char* xt, const Geo& g, 
   }
   const int cnt = __popc(lo) + __popc(hi);   // non-zero dwords of the share
   if (g.dbg & 4) {   // timing experiment: phase 1 only (the impossible count keeps the flags alive)
-    if (cnt == 0x7fffffff) f(0, 0u, own, acc);
+    TieAcc a;
+    a.zero();
+    if (cnt == 0x7fffffff) { f(tau, 0, 0u, a); commit(tau, a); }
     return;
   }
-  const bool heavy = cnt > g.heavy;
+  const int lane = threadIdx.x & 63;
+  const int wave_base = threadIdx.x & ~63;
+  const bool heavy = cnt > QCAP;
+  // ---- compaction of the light shares
+  const unsigned cl_ = heavy ? 0u : (unsigned)cnt;   // 0..QCAP (< 8)
+  unsigned pre = 0, tot = 0;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const uint64_t bal = __ballot((cl_ >> b) & 1u);
+    pre += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
+    tot += (unsigned)__popcll(bal) << b;
+  }
   if (!heavy) {
-    // phase 2: one non-zero count per trip; a new dword is fetched when the current one is used up
-    unsigned d = 0;
-    int off = 0;
-    for (;;) {
-      if (d == 0) {
-        int p;
-        if (lo) { p = __builtin_ctz(lo); lo &= lo - 1; }
-        else if (hi) { p = 32 + __builtin_ctz(hi); hi &= hi - 1; }
-        else break;
-        off = (s + (p >> 2) * S) * 16 + (p & 3) * 4;
-        d = *reinterpret_cast<const unsigned*>(row + off);
-      }
-      const int sh = __builtin_ctz(d) & ~7;
-      const unsigned x = (d >> sh) & 0xffu;
-      d &= ~(0xffu << sh);
-      f(off + (sh >> 3), x, own, acc);
+    unsigned l2 = lo, h2 = hi, j = pre;
+    while (l2 | h2) {
+      int p;
+      if (l2) { p = __builtin_ctz(l2); l2 &= l2 - 1; } else { p = 32 + __builtin_ctz(h2); h2 &= h2 - 1; }
+      wq[j++] = (unsigned short)((lane << 6) | p);
     }
   }
-  uint64_t hm = __ballot(heavy);
-  const int lane = threadIdx.x & 63;
-  while (hm) {   // heavy shares: lane p < 48 takes dword p of the share
-    const int h = __builtin_ctzll(hm);
-    hm &= hm - 1;
-    const Ctx chx = bc(h);
-    const int tau_h = __builtin_amdgcn_readlane(tau, h), s_h = __builtin_amdgcn_readlane(s, h);
-    const unsigned lo_h = __builtin_amdgcn_readlane((int)lo, h), hi_h = __builtin_amdgcn_readlane((int)hi, h);
-    const unsigned char* rowh = xt + tau_h * g.stride;
-    Acc tmp;
-    tmp.zero();
-    const bool mine = lane < 32 ? ((lo_h >> lane) & 1u) : (lane < 48 ? ((hi_h >> (lane - 32)) & 1u) : false);
-    if (mine) {
-      const int off = (s_h + (lane >> 2) * S) * 16 + (lane & 3) * 4;
-      unsigned d = *reinterpret_cast<const unsigned*>(rowh + off);
+  __builtin_amdgcn_wave_barrier();
+  for (unsigned e0 = 0; e0 < tot; e0 += 64) {   // wave-uniform trip count
+    const unsigned e = e0 + lane;
+    if (e < tot) {
+      const unsigned ent = wq[e];
+      const int ls = ent >> 6, p = ent & 63;
+      const int tau_e = (wave_base | ls) >> g.lS, s_e = ls & (S - 1);
+      const int off = (s_e + (p >> 2) * S) * 16 + (p & 3) * 4;
+      unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_e * g.stride + off);
+      TieAcc a;
+      a.zero();
       while (d) {
         const int sh = __builtin_ctz(d) & ~7;
         const unsigned x = (d >> sh) & 0xffu;
         d &= ~(0xffu << sh);
-        f(off + (sh >> 3), x, chx, tmp);
+        f(tau_e, off + (sh >> 3), x, a);
+      }
+      commit(tau_e, a);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- heavy shares: lane p < 48 takes dword p of the share
+  uint64_t hm = __ballot(heavy);
+  while (hm) {
+    const int h = __builtin_ctzll(hm);
+    hm &= hm - 1;
+    const int tau_h = (wave_base | h) >> g.lS, s_h = h & (S - 1);
+    const unsigned lo_h = __builtin_amdgcn_readlane((int)lo, h), hi_h = __builtin_amdgcn_readlane((int)hi, h);
+    TieAcc a;
+    a.zero();
+    const bool mine = lane < 32 ? ((lo_h >> lane) & 1u) : (lane < 48 ? ((hi_h >> (lane - 32)) & 1u) : false);
+    if (mine) {
+      const int off = (s_h + (lane >> 2) * S) * 16 + (lane & 3) * 4;
+      unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_h * g.stride + off);
+      while (d) {
+        const int sh = __builtin_ctz(d) & ~7;
+        const unsigned x = (d >> sh) & 0xffu;
+        d &= ~(0xffu << sh);
+        f(tau_h, off + (sh >> 3), x, a);
       }
     }
-    fin(h, tmp);
+    a.wave_reduce();
+    if (lane == 0) commit(tau_h, a);
   }
 }
 
@@ -648,12 +685,6 @@ struct CountArgs {
   int Gl;   // workgroups per layer of this launch
 };
 
-// what a report needs from its tie: the tie's rho and the LDS offset of the mirrored row
-template <int K>
-struct TieRho {
-  double r[K];
-  int moff;
-};
 template <int K>
 struct SumK {
   double v[K];
@@ -689,13 +720,17 @@ struct TileIter {
   }
 };
 
+#define QBYTES (TPB / 64 * 64 * QCAP * 2)   // the four wave-local queues of a workgroup
+
 template <int K, bool MUT, int PF>
 __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_gamma_counts(CountArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* S1 = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
   double* red = S1 + g.Mp;
-  double* ct = red + 8;
+  double* rt = red + 8;                        // rho of the pair's ties [nt][K]
+  double* ct = rt + (size_t)g.nt * K;          // weight table [Mp][K] (mutuality)
+  unsigned short* wq = reinterpret_cast<unsigned short*>(ct + (MUT ? (size_t)g.Mp * K : 0)) + (threadIdx.x >> 6) * (64 * QCAP);
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
@@ -728,40 +763,33 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_gamma_counts(CountArgs a
     ts.store(xt);
     int i, j;
     const bool act = it.coords(tau, i, j);
-    TieRho<K> own;
-    own.moff = it.mirror(tau) * g.stride;
+    if (s == 0 && tau < g.nt) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) own.r[k] = rn[k];
+      for (int k = 0; k < K; ++k) rt[tau * K + k] = rn[k];
+    }
+    const TileIter cur = it;
     __syncthreads();
     it.next();
     if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }   // flies while this pair is scanned
     if (!(g.dbg & 2)) {
-      scan_tie(xt, g, tau, s, act, own, Pk,
-        [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
-          if (g.dbg & 1) { acc.v[0] += (double)x; return; }
-          double dx = (double)x, sum = 0.0;
+      scan_tile<NoAcc>(xt, g, tau, s, act, wq,
+        [&](int te, int m, unsigned x, NoAcc&) {
+          if (g.dbg & 1) { Pk.v[0] += (double)x; return; }
+          const double dx = (double)x;
+          const double* r = rt + te * K;
+          double sum = 0.0;
           if (MUT) {
             double w[K], cy[K];
-            weights<K>(w, cy, ct, m, (unsigned)xt[c.moff + m]);
+            weights<K>(w, cy, ct, m, (unsigned)xt[cur.mirror(te) * g.stride + m]);
 #pragma unroll
-            for (int k = 0; k < K; ++k) sum += c.r[k] * w[k];
+            for (int k = 0; k < K; ++k) sum += r[k] * w[k];
           } else {
 #pragma unroll
-            for (int k = 0; k < K; ++k) { sum += c.r[k]; acc.v[k] += dx * c.r[k]; }
+            for (int k = 0; k < K; ++k) { sum += r[k]; Pk.v[k] += dx * r[k]; }
           }
           atomicAdd(&S1[m], dx * sum);
         },
-        [&](int h) {
-          TieRho<K> c;
-          c.moff = __builtin_amdgcn_readlane(own.moff, h);
-#pragma unroll
-          for (int k = 0; k < K; ++k) c.r[k] = readlane_f64(own.r[k], h);
-          return c;
-        },
-        [&](int, const SumK<K>& t) {   // block-wide sums: any lane may keep the helpers' share
-#pragma unroll
-          for (int k = 0; k < K; ++k) Pk.v[k] += t.v[k];
-        });
+        [&](int, const NoAcc&) {});
     }
     __syncthreads();
   }
@@ -785,7 +813,9 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) 
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   double* red = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
-  double* ct = red + 8;
+  double* rt = red + 8;
+  double* ct = rt + (size_t)g.nt * K;
+  unsigned short* wq = reinterpret_cast<unsigned short*>(ct + (size_t)g.Mp * K) + (threadIdx.x >> 6) * (64 * QCAP);
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
@@ -803,7 +833,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) 
   const double* rl = a.rho + (size_t)l * g.N * g.N * K;
   TileStream<PF> ts;
   ts.init(g);
-  double rn[K];   // rho of this lane's tie in the NEXT pair (prefetched like the X chunks)
+  double rn[K];
   auto fetch_rho = [&]() {
     int i, j;
     const bool ok = it.coords(tau, i, j);
@@ -816,33 +846,26 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) 
     ts.store(xt);
     int i, j;
     const bool act = it.coords(tau, i, j);
-    TieRho<K> own;
-    own.moff = it.mirror(tau) * g.stride;
+    if (s == 0 && tau < g.nt) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) own.r[k] = rn[k];
+      for (int k = 0; k < K; ++k) rt[tau * K + k] = rn[k];
+    }
+    const TileIter cur = it;
     __syncthreads();
     it.next();
     if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
     if (!(g.dbg & 2)) {
-      scan_tie(xt, g, tau, s, act, own, Pk,
-        [&](int m, unsigned x, const TieRho<K>& c, SumK<K>& acc) {
-          if (g.dbg & 1) { acc.v[0] += (double)x; return; }
-          double dx = (double)x, w[K], cy[K];
-          weights<K>(w, cy, ct, m, (unsigned)xt[c.moff + m]);
+      scan_tile<NoAcc>(xt, g, tau, s, act, wq,
+        [&](int te, int m, unsigned x, NoAcc&) {
+          if (g.dbg & 1) { Pk.v[0] += (double)x; return; }
+          const double dx = (double)x;
+          const double* r = rt + te * K;
+          double w[K], cy[K];
+          weights<K>(w, cy, ct, m, (unsigned)xt[cur.mirror(te) * g.stride + m]);
 #pragma unroll
-          for (int k = 0; k < K; ++k) acc.v[k] += dx * c.r[k] * w[k];
+          for (int k = 0; k < K; ++k) Pk.v[k] += dx * r[k] * w[k];
         },
-        [&](int h) {
-          TieRho<K> c;
-          c.moff = __builtin_amdgcn_readlane(own.moff, h);
-#pragma unroll
-          for (int k = 0; k < K; ++k) c.r[k] = readlane_f64(own.r[k], h);
-          return c;
-        },
-        [&](int, const SumK<K>& t) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) Pk.v[k] += t.v[k];
-        });
+        [&](int, const NoAcc&) {});
     }
     __syncthreads();
   }
@@ -866,12 +889,6 @@ struct RhoArgs {
   int Gl;
 };
 
-struct TieMirror { int moff; };   // rho update: a report only needs the mirrored row
-template <int K>
-struct TieElbo {                  // ELBO: exp(rho) of the tie, its mask row and the mirror's
-  double er[K];
-  int moff, roff, rmoff;
-};
 template <int K>
 struct SumUV {
   double U[K], V[K];
@@ -879,11 +896,18 @@ struct SumUV {
 #pragma unroll
     for (int k = 0; k < K; ++k) { U[k] = 0.0; V[k] = 0.0; }
   }
+  __device__ __forceinline__ void wave_reduce() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { U[k] = wave_sum(U[k]); V[k] = wave_sum(V[k]); }
+  }
 };
-struct SumEQ {   // ELBO scan: log terms (any lane may keep them) and the mirror's masked count (per tie)
-  double v;
+struct SumQ {   // ELBO scan: the mirror tie's masked count
   unsigned q;
-  __device__ __forceinline__ void zero() { v = 0.0; q = 0u; }
+  __device__ __forceinline__ void zero() { q = 0u; }
+  __device__ __forceinline__ void wave_reduce() {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2, 64);
+  }
 };
 
 template <int K, bool MUT, bool UPDATE, bool ELBO, int PF>
@@ -895,17 +919,22 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   double* lut = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 16 * 16 * 8;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
-  double* Gth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
   double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
-  unsigned* qs = reinterpret_cast<unsigned*>(smem + off);
+  // per tie: U[K], V[K] during the update scan; afterwards (ELBO scan) the same bytes hold exp(rho)[K] and Q
+  double* uv = reinterpret_cast<double*>(smem + off);
+  double* ert = uv;
+  unsigned* qs = reinterpret_cast<unsigned*>(uv + (size_t)g.nt * K);
+  off += (size_t)g.nt * 2 * K * 8;
+  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
+  unsigned short* wq = reinterpret_cast<unsigned short*>(smem + off) + (threadIdx.x >> 6) * (64 * QCAP);
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
   const double* Eth = a.par + o.E_th + (size_t)l * g.Mp;
   for (int m = threadIdx.x; m < g.Mp; m += TPB) {
     lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
-    Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
+    if (ELBO) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
   }
   // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3;
   // wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
@@ -927,8 +956,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   // UPDATE: the weights use the current G_nu; stand-alone ELBO: the stale one (model.py:970)
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];
   const double eps = g.eps;
-  double nu_acc = 0.0, e_lin = 0.0, e_q = 0.0;
-  double e_log = 0.0;
+  double nu_acc = 0.0, e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   __syncthreads();
   for (int w = threadIdx.x; w < g.W; w += TPB) {
     double v = 0.0;
@@ -939,7 +967,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
 
   TileIter it;
   it.init(g, p0);
-  const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1), lane = threadIdx.x & 63;
+  const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
   const size_t T = (size_t)g.N * g.N;
   const uint8_t* Xl = a.X + (size_t)l * T * g.Mp;
   const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
@@ -969,9 +997,14 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
     const bool act = it.coords(tau, i, j);
     const size_t tg = act ? ((size_t)i * g.N + j) : 0;
     const int mtau = it.mirror(tau);
+    const TileIter cur = it;
     double lp[K], r[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
+    if (UPDATE && s == 0 && tau < g.nt) {
+#pragma unroll
+      for (int k = 0; k < 2 * K; ++k) uv[tau * 2 * K + k] = 0.0;
+    }
     __syncthreads();
     it.next();
     if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); ms.fetch(Rl, g, it.I * g.b, it.J * g.b); fetch_tie(); }
@@ -987,17 +1020,13 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
     }
     Tt = group_sum(Tt, g.S);
     if (UPDATE) {
-      SumUV<K> uv;
-      uv.zero();
-      TieMirror own;
-      own.moff = mtau * g.stride;
       if (!(g.dbg & 2)) {
-        scan_tie(xt, g, tau, s, act, own, uv,
-          [&](int m, unsigned x, const TieMirror& c, SumUV<K>& acc) {
+        scan_tile<SumUV<K>>(xt, g, tau, s, act, wq,
+          [&](int te, int m, unsigned x, SumUV<K>& acc) {
             if (g.dbg & 1) { acc.U[0] += (double)x; return; }
             const double dx = (double)x, lt = lth[m];
             if (MUT) {
-              const unsigned y = xt[c.moff + m];
+              const unsigned y = xt[cur.mirror(te) * g.stride + m];
               double w[K], cy[K];
               weights<K>(w, cy, ct, m, y);
 #pragma unroll
@@ -1010,23 +1039,20 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
               for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * dx;
             }
           },
-          [&](int h) {
-            TieMirror c;
-            c.moff = __builtin_amdgcn_readlane(own.moff, h);
-            return c;
-          },
-          [&](int h, const SumUV<K>& t) {   // per-tie sums: reduce the helpers' shares, give them to lane h
+          [&](int te, const SumUV<K>& t) {   // the tie's sums live in LDS; a tie belongs to one wave
+            double* d = uv + te * 2 * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-              double su = wave_sum(t.U[k]), sv = MUT ? wave_sum(t.V[k]) : 0.0;
-              if (lane == h) { uv.U[k] += su; uv.V[k] += sv; }
+              atomicAdd(&d[k], t.U[k]);
+              if (MUT) atomicAdd(&d[K + k], t.V[k]);
             }
           });
+        __builtin_amdgcn_wave_barrier();
       }
       double sum = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double u = group_sum(uv.U[k], g.S);
+        const double u = (tau < g.nt) ? uv[tau * 2 * K + k] : 0.0;
         r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
         sum += r[k];
       }
@@ -1034,56 +1060,41 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] /= sum;
       }
-      if (act) {
-        if (s == 0) {
+      if (act && s == 0) {
 #pragma unroll
-          for (int k = 0; k < K; ++k) rl[tg * K + k] = r[k];
-        }
-        if (MUT) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) nu_acc += uv.V[k] * r[k];   // this lane's share of model.py:822-825
+        for (int k = 0; k < K; ++k) {
+          rl[tg * K + k] = r[k];
+          if (MUT) nu_acc += uv[tau * 2 * K + K + k] * r[k];   // the tie's share of model.py:822-825
         }
       }
     }
     if (ELBO) {
-      TieElbo<K> own;
+      if (UPDATE) __syncthreads();   // every wave is done with U,V before the bytes are reused
+      if (s == 0 && tau < g.nt) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) own.er[k] = exp(r[k]);   // exp(rho), model.py:971
-      own.moff = mtau * g.stride; own.roff = tau * g.W; own.rmoff = mtau * g.W;
-      SumEQ eq;
-      eq.zero();
-      scan_tie(xt, g, tau, s, act, own, eq,
-        [&](int m, unsigned x, const TieElbo<K>& c, SumEQ& acc) {
+        for (int k = 0; k < K; ++k) ert[tau * K + k] = exp(r[k]);   // exp(rho), model.py:971
+        qs[tau] = 0u;
+      }
+      __syncthreads();
+      scan_tile<SumQ>(xt, g, tau, s, act, wq,
+        [&](int te, int m, unsigned x, SumQ& acc) {
           const double dx = (double)x;
-          const unsigned y = MUT ? (unsigned)xt[c.moff + m] : 0u;
-          const bool in_r = (rw[c.roff + (m >> 6)] >> (m & 63)) & 1ull;
+          const int mt = cur.mirror(te);
+          const unsigned y = MUT ? (unsigned)xt[mt * g.stride + m] : 0u;
+          const bool in_r = (rw[te * g.W + (m >> 6)] >> (m & 63)) & 1ull;
           double inner = 0.0;
           if (in_r) {
-            const double z2 = gnu * (double)y;
+            const double z2 = gnu * (double)y, gt = Gth[m];
+            const double* er = ert + te * K;
 #pragma unroll
-            for (int k = 0; k < K; ++k) inner += c.er[k] * (Gth[m] * Gla[k] + z2);
+            for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
           }
-          acc.v += dx * log(inner + eps);
-          if (MUT && ((rw[c.rmoff + (m >> 6)] >> (m & 63)) & 1ull)) acc.q += x;   // R[mirror] X^T[mirror]
+          e_log += dx * log(inner + eps);
+          if (MUT && ((rw[mt * g.W + (m >> 6)] >> (m & 63)) & 1ull)) acc.q += x;   // R[mirror] X^T[mirror]
         },
-        [&](int h) {
-          TieElbo<K> c;
-#pragma unroll
-          for (int k = 0; k < K; ++k) c.er[k] = readlane_f64(own.er[k], h);
-          c.moff = __builtin_amdgcn_readlane(own.moff, h); c.roff = __builtin_amdgcn_readlane(own.roff, h);
-          c.rmoff = __builtin_amdgcn_readlane(own.rmoff, h);
-          return c;
-        },
-        [&](int h, const SumEQ& t) {
-          eq.v += t.v;
-          unsigned tq = t.q;
-#pragma unroll
-          for (int o2 = 32; o2 > 0; o2 >>= 1) tq += __shfl_xor(tq, o2, 64);
-          if (lane == h) eq.q += tq;
+        [&](int te, const SumQ& t) {   // Q of the MIRROR tie: sum_m R[mirror,m] X[this,m]; the mirror may belong to another wave
+          if (t.q) atomicAdd(&qs[cur.mirror(te)], t.q);
         });
-      e_log += eq.v;
-      const unsigned qtot = group_sum_u(eq.q, g.S);
-      if (act && s == 0) qs[mtau] = qtot;   // Q of the MIRROR tie: sum_m R[mirror,m] X[this,m]
       __syncthreads();
       if (act && s == 0) {
         double sr = 0.0, se = 0.0, ent = 0.0;
@@ -1235,11 +1246,20 @@ static int fail(vmr_handle h, int code, const char* msg) {
 }
 
 static size_t shmem_ct(const Geo& g) { return g.mut ? (size_t)g.Mp * g.K * 8 : 0; }
-static size_t shmem_counts(const Geo& g) { return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + shmem_ct(g); }
-static size_t shmem_phi(const Geo& g) { return (size_t)g.nt * g.stride + 64 + shmem_ct(g); }
-static size_t shmem_rho(const Geo& g) {
-  return (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.W * 8 +
-         (size_t)g.Mp * 16 + 64 + shmem_ct(g) + (size_t)g.nt * 4 + 16;
+static size_t shmem_q() { return (size_t)(TPB / 64) * 64 * QCAP * 2; }
+static size_t shmem_counts(const Geo& g) {
+  return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + (size_t)g.nt * g.K * 8 + shmem_ct(g) + shmem_q();
+}
+static size_t shmem_phi(const Geo& g) {
+  return (size_t)g.nt * g.stride + 64 + (size_t)g.nt * g.K * 8 + shmem_ct(g) + shmem_q();
+}
+static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
+  size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.W * 8 +
+             (size_t)g.Mp * 8 + 64 + shmem_ct(g) + shmem_q();
+  n += (size_t)g.nt * 2 * g.K * 8;   // U,V / exp(rho),Q per tie
+  if (elbo) n += (size_t)g.Mp * 8;
+  (void)update;
+  return n + 16;
 }
 
 struct Prof {
@@ -1302,7 +1322,7 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
 static int launch_gamma(vmr_ctx* h) {
   const Geo& g = h->g;
   // fork: the mask half (memory/latency-bound, few VALU ops) overlaps the counts half (VALU-bound)
-  hipStream_t ms = h->stream2;
+  hipStream_t ms = h->serial ? h->stream : h->stream2;   // VMR_SERIAL=1: no overlap (kernel timing experiments)
   HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
   HIPCHK(h, hipStreamWaitEvent(ms, h->ev_fork, 0));
   {
@@ -1362,7 +1382,7 @@ static int launch_phi(vmr_ctx* h) {
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   const Geo& g = h->g;
   RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, 1};
-  size_t sm = shmem_rho(g);
+  size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
   // the nu sub-step may be skipped by a caller: start from clean slots when nobody consumed them
@@ -1452,6 +1472,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   const size_t rows = (size_t)L * N * N;
   const size_t raw = rows * M;
   h->ncu = prop.multiProcessorCount;
+  h->serial = getenv("VMR_SERIAL") != nullptr;
   const size_t slack = (size_t)g.b * N + g.b;   // tile streams may read (never use) rows past the last tie
   CCHK(hipMalloc(&h->X, (rows + slack) * g.Mp));
   CCHK(hipMemsetAsync(h->X + rows * g.Mp, 0, slack * g.Mp, h->stream));
