@@ -168,14 +168,14 @@ def main():
             "elbo": elbos, "gen_seconds": t_gen,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds)
+            out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds, eng)
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, net, R, host, pr, budget_s):
+def cpu_baseline(cfg, net, R, host, pr, budget_s, eng):
     """The plain-C oracle (oracle/cavi_ref.c, OpenMP) on the same inputs and initial state, timed on
     this box's host cores for a bounded number of sweeps.  The reference's own NumPy path cannot run
     this configuration at all, so kind = "port"."""
@@ -193,9 +193,22 @@ def cpu_baseline(cfg, net, R, host, pr, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 50 or el / n * (n + 1) > 2 * budget_s:
             break
-    return {"value": n / el, "unit": "iter/s", "cores": cores, "kind": "port",
+    base = {"value": n / el, "unit": "iter/s", "cores": cores, "kind": "port",
             "sample": f"{n} full sweeps (gamma,phi,rho,nu; no ELBO) of the same {cfg['L']}x{cfg['N']}x{cfg['N']}x{cfg['M']} "
                       f"workload with oracle/cavi_ref.c (OpenMP, {cores} threads), {el:.1f} s"}
+    # full-size parity (outside every timed region): the engine, restarted from the same state, after the same
+    # n sweeps, against the C oracle's ELBO and posteriors
+    e_cpu = c.elbo()
+    eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+    e_gpu = eng.step(n, want_elbo=True)
+    st = eng.get_state(rho=True)
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
+    parity = {"sweeps": n, "elbo_gpu": e_gpu, "elbo_cpu_oracle": e_cpu, "elbo_rel_err": abs(e_gpu - e_cpu) / abs(e_cpu),
+              "gamma_shp_rel": rel(st["gamma_shp"], c.gamma_shp), "gamma_rte_rel": rel(st["gamma_rte"], c.gamma_rte),
+              "phi_shp_rel": rel(st["phi_shp"], c.phi_shp), "phi_rte_rel": rel(st["phi_rte"], c.phi_rte),
+              "nu_shp_rel": abs(st["nu_shp"] - c.nu_shp) / abs(c.nu_shp),
+              "rho_max_abs": float(np.max(np.abs(st["rho"] - c.rho)))}
+    return base, parity
 
 
 if __name__ == "__main__":
