@@ -65,3 +65,24 @@ def test_sparse_container_and_device_tensor_inputs_agree():
     for other in (b, c):
         assert abs(other.maxL - a.maxL) <= 1e-9 * abs(a.maxL)
         np.testing.assert_allclose(other.rho_f, a.rho_f, rtol=1e-9, atol=1e-14)
+
+
+def test_fit_from_edgelist_dataframe():
+    """`fit(DataFrame)` (reference model.py:107-124, test/test_model.py:466-481): the village-1 'money' edgelist
+    gives the fit the reference gets from the same data (golden case I)."""
+    import os
+    import pandas as pd
+    from tests.golden_util import GOLDEN
+    from vimure_amd import VimureModel
+    J = dict(np.load(os.path.join(GOLDEN, "J_edgelist_io.npz")))
+    df = pd.DataFrame({c: J["vil1_df_" + c] for c in ("reporter", "ego", "alter", "weight", "layer")})
+    d = load_case("I_karnataka_vil1_money")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel().fit(df, seed=1, num_realisations=1, max_iter=21)
+    assert (m.L, m.N, m.M, m.K) == (1, 324, 324, 2)
+    assert m.trace["iter"].tolist() == d["fit_trace_iter"].tolist()
+    assert abs(m.maxL - float(d["fit_maxL"])) <= 1e-8 * abs(float(d["fit_maxL"]))
+    np.testing.assert_allclose(m.rho_f, d["fit_rho_f"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(m.G_exp_nu_f, d["fit_G_exp_nu_f"], rtol=1e-6)
+    assert list(m.layerNames) == ["money"] and len(m.nodeNames) == 324

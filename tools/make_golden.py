@@ -205,5 +205,50 @@ def main():
     np.savez_compressed(path, **d)
 
 
-if __name__ == "__main__":
+def io_cases():
+    """Edgelist ingestion vectors (reference _io.py:132-295): a small synthetic survey and Karnataka village 1."""
+    g = np.random.RandomState(5)
+    names = [f"n{i:02d}" for i in range(14)]
+    rows = []
+    for rep in names[:10]:
+        for _ in range(g.randint(2, 7)):
+            other = names[g.randint(len(names))]
+            if other == rep:
+                continue
+            e, a = (rep, other) if g.rand() < 0.5 else (other, rep)
+            rows.append((rep, e, a, ["borrow", "advice"][g.randint(2)], int(g.randint(0, 4))))
+    df = pd.DataFrame(rows, columns=["reporter", "ego", "alter", "layer", "weight"])
+    out = {}
+    for tag, kw in (("plain", {}), ("weighted", dict(is_weighted=True)), ("undirected", dict(is_undirected=True, is_weighted=True)),
+                    ("lists", dict(nodes=sorted(names), reporters=sorted(names[:10]), K=3))):
+        net = vm._io.read_from_edgelist(df.copy(), **kw)
+        out[f"{tag}_X_subs"] = np.stack(net.X.subs).astype(np.int32)
+        out[f"{tag}_X_vals"] = np.asarray(net.X.vals).astype(np.int64)
+        out[f"{tag}_R_subs"] = np.stack(net.R.subs).astype(np.int32)
+        out[f"{tag}_shape"] = np.array(net.X.shape)
+        out[f"{tag}_LNMK"] = np.array([net.L, net.N, net.M, net.K])
+        out[f"{tag}_nodes"] = np.array(net.nodeNames["name"].tolist())
+        out[f"{tag}_layers"] = np.array(net.layerNames)
+    for c in df.columns:
+        out["df_" + c] = df[c].values.astype(str) if df[c].dtype == object else df[c].values
+    sys.path.insert(0, "/root/reference/notebooks/python/experiments/")
+    from karnataka import read_village_data
+    kdf, _, _ = read_village_data("vil1", filter_layer="money", print_details=False,
+                                  data_folder="/root/reference/data/input/india_microfinance/formatted/")
+    kdf.rename(columns={"Ego": "ego", "Alter": "alter"}, inplace=True)
+    for c in kdf.columns:
+        out["vil1_df_" + c] = kdf[c].values.astype(str) if kdf[c].dtype == object else kdf[c].values
+    net = vm._io.read_from_edgelist(kdf.copy(), K=2)
+    out["vil1_LNMK"] = np.array([net.L, net.N, net.M, net.K])
+    out["vil1_nodes"] = np.array(net.nodeNames["name"].tolist())
+    np.savez_compressed(os.path.join(OUT, "J_edgelist_io.npz"), **out)
+    print("J_edgelist_io: rows", len(df), "vil1 rows", len(kdf), "vil1 LNMK", out["vil1_LNMK"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "io":
+    io_cases()
+
+
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+    io_cases()
