@@ -38,7 +38,7 @@ DEFAULT_NUM_REALISATIONS = 1
 
 _EXTRA = ["R", "EPS", "K", "bias0", "max_iter", "alpha_lambda", "beta_lambda", "alpha_teta", "beta_teta",
           "num_realisations"]  # the reference's whitelist, typos included (model.py:90-101)
-_OURS = ["device", "alpha_theta", "beta_theta"]
+_OURS = ["device", "alpha_theta", "beta_theta", "engine"]
 
 
 def _is_torch(x):
@@ -215,10 +215,16 @@ class VimureModel(TransformerMixin, BaseEstimator):
     # ------------------------------------------------------------------ fit (model.py:327-448)
     def fit(self, X, theta_prior=(0.1, 0.1), lambda_prior=(10.0, 10.0), eta_prior=(0.5, 1.0), rho_prior=None,
             seed: int = None, **extra_params):
-        """Same contract as the reference's `fit`; extra keyword `device` picks the GPU (default 0,
-        or the device of a torch tensor X)."""
+        """Same contract as the reference's `fit`; extra keywords: `device` picks the GPU (default 0, or the
+        device of a torch tensor X); `engine` reuses a `CaviEngine` already holding this X, R, K (many seeds
+        of one dataset: the data is uploaded once, see vimure_amd/batch.py)."""
         Xd, Rd = self._check_fit_params(X, lambda_prior, theta_prior, eta_prior, rho_prior, seed, **extra_params)
-        eng = CaviEngine(Xd, Rd, K=self.K, mutuality=self.mutuality, eps=self.EPS, device=extra_params.get("device"))
+        eng = extra_params.get("engine")
+        own_engine = eng is None
+        if own_engine:
+            eng = CaviEngine(Xd, Rd, K=self.K, mutuality=self.mutuality, eps=self.EPS, device=extra_params.get("device"))
+        elif (eng.L, eng.N, eng.M, eng.K, eng.mutuality) != (self.L, self.N, self.M, self.K, bool(self.mutuality)):
+            raise ValueError("engine does not match the shape / K / mutuality of this fit")
         try:
             self.sumX, coverage = eng.data_stats()
             eng.set_priors(self.alpha_theta, self.beta_theta, self.alpha_lambda, self.beta_lambda,
@@ -256,7 +262,8 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 step = self.prng.randint(1, 500)
                 self._change_seed(step if self.seed is None else self.seed + step)
         finally:
-            eng.close()
+            if own_engine:
+                eng.close()
         cols = ["realisation", "seed", "iter", "elbo", "runtime", "reached_convergence"]
         self.trace = pd.DataFrame(trace, columns=cols)
         self.maxL = maxL
