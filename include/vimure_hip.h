@@ -103,6 +103,19 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out);
  * model.py:970).  Synchronises.  Returns VMR_ENAN when the value is NaN. */
 int vmr_elbo(vmr_handle h, double* out);
 
+/* Fits whose LAYERS are spread over several handles / GPUs (BASELINE config 5).  nu is one scalar shared by
+ * all layers (model.py:589-596, 822-825) and the ELBO stop rule is joint (model.py:1039-1047), so the owners
+ * exchange three doubles per sweep:
+ *   vmr_sweep_local runs gamma, phi, rho on the local layers, does NOT commit nu, synchronises and returns
+ *     out3[0] = local sum x w2 rho (the local part of nu_shp - alpha_eta),
+ *     out3[1] = local ELBO terms that do not involve nu (only when want_elbo; data, entropy, theta/lambda Gamma terms),
+ *     out3[2] = local sum_t (sum_k rho_k) Q_t  (enters the ELBO as -E[nu] * total; only when want_elbo);
+ *   the caller sums the three over all owners (2-3 doubles all-reduce, latency-bound) and gives every owner
+ *   vmr_commit_nu(total of out3[0]).  ELBO = total out3[1] - E[nu] * total out3[2] + Gamma term of nu
+ *   (model.py:1006-1011), with nu_rte = beta_eta + sum of X over ALL layers set through vmr_set_state. */
+int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3);
+int vmr_commit_nu(vmr_handle h, double nu_partial_total);
+
 /* One update of a sweep (test hook for step-level parity with model.py:643-656). */
 int vmr_sub_step(vmr_handle h, int which);
 

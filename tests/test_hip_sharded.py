@@ -1,0 +1,51 @@
+"""GPU, 2 processes: a two-layer fit with one layer per process (layer-sharded mode, 3-double all-reduce per
+sweep over gloo) reproduces the reference's joint two-layer fit (golden case B: K = 3, random mask, mutuality)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from tests.golden_util import case_config, load_case
+    from vimure_amd.sharded import fit_layer_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = load_case("B_random_mask_K3")
+    K, mut, und, seed, priors, fitargs, rho_prior = case_config(d)
+    res = fit_layer_sharded(d["X"][rank:rank + 1], d["R"][rank:rank + 1], [rank], 2, K, dist, seed=seed, mutuality=mut,
+                            device=0, **fitargs)
+    q.put((rank, [t[2] for t in res["trace"]], [t[3] for t in res["trace"]], [t[1] for t in res["trace"]],
+           res["maxL"], res["posterior"]["rho"], res["posterior"]["nu_shp"], res["next_seed"]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_layer_each_equal_the_joint_fit():
+    import torch.multiprocessing as mp
+    from tests.golden_util import load_case
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = load_case("B_random_mask_K3")
+    for rank, iters, elbos, seeds, maxL, rho, nu_shp, next_seed in got:
+        assert iters == d["fit_trace_iter"].tolist() and seeds == d["fit_trace_seed"].tolist()
+        ref = d["fit_trace_elbo"]
+        assert np.all(np.abs(np.array(elbos) - ref) <= 1e-8 * np.maximum(1.0, np.abs(ref)))
+        assert abs(maxL - float(d["fit_maxL"])) <= 1e-8 * abs(float(d["fit_maxL"]))
+        np.testing.assert_allclose(rho[0], d["fit_rho_f"][rank], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(nu_shp, d["fit_nu_shp_f"], rtol=1e-7)
+        assert next_seed == int(d["fit_final_seed"])

@@ -29,6 +29,8 @@ SIGNATURES = {
     "vmr_step": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_elbo": (C.c_int, [C.c_void_p, _dp]),
     "vmr_sub_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "vmr_sweep_local": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "vmr_commit_nu": (C.c_int, [C.c_void_p, C.c_double]),
     "vmr_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "vmr_get_geometric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vmr_sync": (C.c_int, [C.c_void_p]),

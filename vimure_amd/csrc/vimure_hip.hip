@@ -1234,6 +1234,22 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* slotR, dou
       e += gamma_elbo_term(sc[SC_A_ETA], sc[SC_B_ETA], sc[SC_NU_SHP], sc[SC_NU_RTE]);
       elbo_out[0] = e;
     }
+    // raw pieces for fits whose layers are spread over several handles (vmr_sweep_local)
+    elbo_out[1] = a0;             // sum x w2 rho over the local layers (nu_shp - alpha_eta)
+    elbo_out[2] = a1 + a2 + gt;   // local ELBO terms that do not involve nu
+    elbo_out[3] = a3;             // local sum_t (sum_k rho) Q_t, enters the ELBO as -E[nu] * (.)
+  }
+}
+
+// commit a nu_shp that was summed over several handles (layer-sharded fits)
+__global__ void k_commit_nu(double* par, double nu_partial_total, Geo g) {
+  const ParOff o = par_off(g.L, g.Mp, g.K);
+  double* sc = par + o.sc;
+  if (threadIdx.x == 0 && blockIdx.x == 0 && g.mut) {
+    sc[SC_G_NU_STALE] = sc[SC_G_NU];
+    sc[SC_NU_SHP] = sc[SC_A_ETA] + nu_partial_total;
+    sc[SC_G_NU] = exp(digamma_pos(sc[SC_NU_SHP]) - log(sc[SC_NU_RTE]));
+    sc[SC_E_NU] = sc[SC_NU_SHP] / sc[SC_NU_RTE];
   }
 }
 
@@ -1630,6 +1646,36 @@ int vmr_elbo(vmr_handle h, double* out) {
   int rc;
   if ((rc = launch_rho(h, 2, false))) return rc;
   return read_elbo(h, out);
+}
+
+int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
+  if (!h || !out3) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sweep_local");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = launch_gamma(h))) return rc;
+  if ((rc = launch_phi(h))) return rc;
+  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;   // rho updated, nu NOT committed
+  if (!want_elbo) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
+    Prof p(h, VMR_KERNEL_FINALIZE);
+    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev, 0, 0, h->g);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->slotR_dirty = false;   // consumed by k_fin_rho either way
+  double v[4];
+  HIPCHK(h, hipMemcpyAsync(v, h->elbo_dev, 32, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out3[0] = v[1]; out3[1] = v[2]; out3[2] = v[3];
+  return VMR_OK;
+}
+
+int vmr_commit_nu(vmr_handle h, double nu_partial_total) {
+  if (!h) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_commit_nu");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_commit_nu, dim3(1), dim3(64), 0, h->stream, h->par, nu_partial_total, h->g);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
 }
 
 int vmr_sub_step(vmr_handle h, int which) {

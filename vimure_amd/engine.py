@@ -129,6 +129,15 @@ class CaviEngine:
         self._check(self.lib.vmr_elbo(self._h, C.byref(e)))
         return e.value
 
+    def sweep_local(self, want_elbo=False):
+        """Layer-sharded fits: one sweep on the local layers without committing nu -> (nu_partial, elbo_main, elbo_q)."""
+        out = (C.c_double * 3)()
+        self._check(self.lib.vmr_sweep_local(self._h, int(want_elbo), out))
+        return out[0], out[1], out[2]
+
+    def commit_nu(self, nu_partial_total):
+        self._check(self.lib.vmr_commit_nu(self._h, float(nu_partial_total)))
+
     def sub_step(self, which):
         self._check(self.lib.vmr_sub_step(self._h, int(which)))
 
