@@ -83,7 +83,8 @@ def main():
     net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=cfg["avg_degree"], sparsify=True, eta=cfg["eta"],
                        seed=0, device=dev)
     R = torch.ones((L, N, N, M), dtype=torch.uint8, device=dev)  # "multiply reported": dense all-ones mask, streamed
-    nnz = int((net.X != 0).sum().item())
+    nnz = sum(int(torch.count_nonzero(net.X[l]).item()) for l in range(L))
+    torch.cuda.empty_cache()
     t_gen = time.time() - t_gen
     eng = CaviEngine(net.X, R, K=K, mutuality=cfg["mutuality"], device=local)
     sum_x, cov = eng.data_stats()

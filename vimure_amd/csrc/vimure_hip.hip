@@ -83,6 +83,7 @@ struct vmr_ctx {
   // partials
   double *slotS1 = nullptr, *slotA = nullptr, *slotP = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
   double* elbo_dev = nullptr;  // [0] elbo
+  double* lutg = nullptr;      // wide masks (W > 4): the nibble LUT of E[theta] lives in global memory [L][W*256]
   bool have_priors = false, have_state = false;
   bool slotR_dirty = false;
   bool serial = false;
@@ -540,6 +541,22 @@ __global__ void k_init_rho(const double* __restrict__ pr, double* __restrict__ r
   }
 }
 
+// nibble LUT of E[theta] for wide masks: lut[l][n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3
+__global__ void k_build_lut(const double* __restrict__ par, double* __restrict__ lutg, Geo g) {
+  const ParOff o = par_off(g.L, g.Mp, g.K);
+  const int l = blockIdx.x;
+  const double* Eth = par + o.E_th + (size_t)l * g.Mp;
+  for (int q = threadIdx.x; q < g.W * 256; q += blockDim.x) {
+    int n = q >> 4, e = q & 15;
+    double v = 0.0;
+    for (int u = 0; u < 4; ++u) {
+      int m = n * 4 + u;
+      if (((e >> u) & 1) && m < g.Mp) v += Eth[m];
+    }
+    lutg[(size_t)l * g.W * 256 + q] = v;
+  }
+}
+
 // derived expectations of all Gamma factors from shp/rte (used after vmr_set_state)
 __global__ void k_derive_all(double* par, Geo g) {
   ParOff o = par_off(g.L, g.Mp, g.K);
@@ -886,6 +903,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) 
 struct RhoArgs {
   const uint8_t* X; const uint64_t* Rb; double* rho; const double* logpr; const double* par;
   double* slotR;
+  const double* lutg;   // global nibble LUT when W > 4, else NULL (LUT built in LDS)
   int Gl;
 };
 
@@ -916,7 +934,8 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   unsigned char* xt = smem;
   size_t off = (size_t)g.nt * g.stride;
   uint64_t* rw = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)g.nt * g.W * 8;
-  double* lut = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 16 * 16 * 8;
+  const bool lut_lds = (a.lutg == nullptr);
+  double* lut_s = reinterpret_cast<double*>(smem + off); off += lut_lds ? (size_t)g.W * 16 * 16 * 8 : 0;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
@@ -936,18 +955,21 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
     lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
     if (ELBO) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
   }
-  // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3;
-  // wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
-  for (int q = threadIdx.x; q < g.W * 16 * 16; q += TPB) {
-    int n = q >> 4, e = q & 15;
-    double v = 0.0;
+  // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3 (LDS, or global for
+  // wide masks); wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
+  if (lut_lds) {
+    for (int q = threadIdx.x; q < g.W * 16 * 16; q += TPB) {
+      int n = q >> 4, e = q & 15;
+      double v = 0.0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int m = n * 4 + u;
-      if ((e >> u) & 1) v += (m < g.Mp) ? Eth[m] : 0.0;
+      for (int u = 0; u < 4; ++u) {
+        int m = n * 4 + u;
+        if ((e >> u) & 1) v += (m < g.Mp) ? Eth[m] : 0.0;
+      }
+      lut_s[q] = v;
     }
-    lut[q] = v;
   }
+  const double* lut = lut_lds ? lut_s : a.lutg + (size_t)l * g.W * 256;
   double Ela[K], lla[K], Gla[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -1270,7 +1292,7 @@ static size_t shmem_phi(const Geo& g) {
   return (size_t)g.nt * g.stride + 64 + (size_t)g.nt * g.K * 8 + shmem_ct(g) + shmem_q();
 }
 static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
-  size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 16 * 16 * 8 + (size_t)g.W * 8 +
+  size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (g.W > 4 ? 0 : (size_t)g.W * 16 * 16 * 8) + (size_t)g.W * 8 +
              (size_t)g.Mp * 8 + 64 + shmem_ct(g) + shmem_q();
   n += (size_t)g.nt * 2 * g.K * 8;   // U,V / exp(rho),Q per tie
   if (elbo) n += (size_t)g.Mp * 8;
@@ -1369,6 +1391,7 @@ static int launch_gamma(vmr_ctx* h) {
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->slotS1, h->slotA, h->slotP, g);
+    if (h->lutg) hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -1397,7 +1420,7 @@ static int launch_phi(vmr_ctx* h) {
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   const Geo& g = h->g;
-  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, 1};
+  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
@@ -1525,6 +1548,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     CCHK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CCHK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
   }
   CCHK(hipMalloc(&h->elbo_dev, 8 * 8));
+  if (g.W > 4) CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
   CCHK(hipStreamSynchronize(h->stream));
 #undef CCHK
   *out = h;
@@ -1536,7 +1560,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotS1, h->slotA, h->slotP, h->slotR, h->elbo_dev};
+  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotS1, h->slotA, h->slotP, h->slotR, h->elbo_dev, h->lutg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1607,6 +1631,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   }
   hipLaunchKernelGGL(k_init_rho, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, n, g.eps);
   hipLaunchKernelGGL(k_derive_all, dim3(8), dim3(256), 0, h->stream, h->par, g);
+  if (h->lutg) hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
@@ -1620,6 +1645,15 @@ static int read_elbo(vmr_ctx* h, double* out) {
   return VMR_OK;
 }
 
+static int sweep(vmr_ctx* h, int mode) {
+  // (hipGraph replay of the sweep was tried: 58 vs 63 us per sweep on a 100-node network -- the small-fit
+  //  regime is bound by the kernels' own fixed costs, not by launch calls; kept eager.)
+  int rc;
+  if ((rc = launch_gamma(h))) return rc;
+  if ((rc = launch_phi(h))) return rc;
+  return launch_rho(h, mode, true);
+}
+
 int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_step");
@@ -1627,10 +1661,8 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   for (int it = 0; it < n_iters; ++it) {
-    if ((rc = launch_gamma(h))) return rc;
-    if ((rc = launch_phi(h))) return rc;
     bool last = (it == n_iters - 1) && elbo_out;
-    if ((rc = launch_rho(h, last ? 1 : 0, true))) return rc;
+    if ((rc = sweep(h, last ? 1 : 0))) return rc;
   }
   if (elbo_out) {
     if (n_iters == 0) return vmr_elbo(h, elbo_out);

@@ -54,7 +54,7 @@ def self_reporter_mask(L, N, M, reporters=None):
 
 
 def standard_sbm(N=100, M=100, L=1, K=2, C=2, avg_degree=2.0, sparsify=True, eta=0.5, sh_theta=2.0, sc_theta=0.5,
-                 flag_self_reporter=False, lambda_diff=None, theta=None, seed=0, device=None):
+                 flag_self_reporter=False, lambda_diff=None, theta=None, seed=0, device=None, block_bytes=2.0e9):
     """Ground truth + observed reports.  device=None -> NumPy on the host; 'cuda[:i]' -> torch on that GPU
     (X and R stay on the device as uint8 tensors, ready for CaviEngine / VimureModel.fit)."""
     if eta < 0 or eta >= 1:
@@ -101,30 +101,46 @@ def standard_sbm(N=100, M=100, L=1, K=2, C=2, avg_degree=2.0, sparsify=True, eta
     MYt = torch.as_tensor(MY, device=dev, dtype=torch.float32)
     X = torch.zeros((L, N, N, M), dtype=torch.uint8, device=dev)
     Ys, lams = [], []
-    iu = torch.triu(torch.ones((N, N), dtype=torch.bool, device=dev), 1)[:, :, None]
+    # row blocks small enough that a [B,B,M] float32 temporary stays near 2 GB (config 5: N=8000, M=1000 -> B=724)
+    B = int(min(N, max(1, int((block_bytes / (4.0 * M)) ** 0.5))))
+    starts = list(range(0, N, B))
     for l in range(L):
         Y = torch.poisson(MYt, generator=gen)
         Y.fill_diagonal_(0)
         Y.clamp_(max=K - 1)
         lam = torch.where(Y > 0, torch.full_like(Y, 0.01 + lambda_diff) if lambda_diff is not None else Y,
                           torch.full_like(Y, 0.01))
-        MX = lam[:, :, None] * th[l][None, None, :]             # [N,N,M]
-        MXt = MX.transpose(0, 1)
-        A = torch.poisson((MX + eta * MXt) / (1.0 - eta * eta), generator=gen)
-        B = torch.poisson(MX + eta * A.transpose(0, 1), generator=gen)
-        first_ij = torch.rand((N, N, M), device=dev, generator=gen) < 0.5
-        fu = first_ij & iu
-        fl = (~first_ij & iu).transpose(0, 1)
-        is_first = fu | fl
-        is_second = is_first.transpose(0, 1)
-        Xl = torch.where(is_first, A, torch.where(is_second, B, torch.zeros_like(A)))
-        X[l] = Xl.clamp_(max=255).to(torch.uint8)
+        for bi, i0 in enumerate(starts):
+            i1 = min(N, i0 + B)
+            for j0 in starts[bi:]:
+                j1 = min(N, j0 + B)
+                MXa = lam[i0:i1, j0:j1, None] * th[l][None, None, :]            # block (I,J)
+                MXb = lam[j0:j1, i0:i1, None] * th[l][None, None, :]            # block (J,I)
+                Aa = torch.poisson((MXa + eta * MXb.transpose(0, 1)) / (1.0 - eta * eta), generator=gen)
+                # on a diagonal block (J,I) IS (I,J): one draw serves both directions
+                Ab = Aa if i0 == j0 else torch.poisson((MXb + eta * MXa.transpose(0, 1)) / (1.0 - eta * eta), generator=gen)
+                Ba = torch.poisson(MXa + eta * Ab.transpose(0, 1), generator=gen)   # second draw given the mirror's first
+                Bb = torch.poisson(MXb + eta * Aa.transpose(0, 1), generator=gen)
+                coin = torch.rand(MXa.shape, device=dev, generator=gen) < 0.5     # (i,j) drawn first, else (j,i)
+                gi = torch.arange(i0, i1, device=dev)[:, None, None]
+                gj = torch.arange(j0, j1, device=dev)[None, :, None]
+                up = gi < gj                                                      # i < j: this element leads its pair
+                lo = gi > gj
+                if i0 == j0:   # diagonal block: both triangles live in the same block
+                    coin_t = coin.transpose(0, 1)
+                    Xa = torch.where(up & coin, Aa, torch.where(up & ~coin, Ba,
+                         torch.where(lo & coin_t, Ba, torch.where(lo & ~coin_t, Aa, torch.zeros_like(Aa)))))
+                    X[l, i0:i1, j0:j1] = Xa.clamp_(max=255).to(torch.uint8)
+                else:          # every (i,j) of the block has i < j
+                    X[l, i0:i1, j0:j1] = torch.where(coin, Aa, Ba).clamp_(max=255).to(torch.uint8)
+                    X[l, j0:j1, i0:i1] = torch.where(coin.transpose(0, 1), Bb, Ab).clamp_(max=255).to(torch.uint8)
+                del MXa, MXb, Aa, Ab, Ba, Bb, coin
         Ys.append(Y.to(torch.uint8))
         lams.append(lam)
-        del A, B, MX, MXt, first_ij, fu, fl, is_first, is_second, Xl
     R = None
     if flag_self_reporter:
         R = torch.as_tensor(self_reporter_mask(L, N, M), device=dev)
         X = X * R
-    torch.cuda.synchronize(dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
     return SyntheticNetwork(X, R, torch.stack(Ys), np.asarray(theta), torch.stack(lams), eta, K)
