@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               atomicAdd(&d[k], t.U[k]);
-              if (MUT) atomicAdd(&d[K + k], t.V[k]);
+              if (MUT && t.V[k] != 0.0) atomicAdd(&d[K + k], t.V[k]);   // only reports with a mirror count feed nu
             }
           });
         __builtin_amdgcn_wave_barrier();
