@@ -9,7 +9,7 @@
 // Kernel families
 //   k_gamma_mask   lane <-> reporter m, tie wave-uniform: R-row words arrive by scalar loads and
 //                  become the EXEC mask of K v_add_f64 -- A[l,m,k] = sum_ij R[l,i,j,m] rho[l,i,j,k].
-//   k_gamma_counts / k_phi / k_rho   "tile-pair" sweeps over X: a workgroup stages the (I,J) tile
+//   k_hist / k_rho   "tile-pair" sweeps over X: a workgroup stages the (I,J) tile
 //                  of ties and its mirror (J,I) in LDS so that X[l,j,i,m] (the reference's
 //                  data_T_vals) is an LDS byte read; S lanes own one tie row, skip zero 16-B
 //                  chunks and run the per-report arithmetic only on non-zero counts.
@@ -56,6 +56,7 @@ struct Geo {
   long long P;  // tile pairs per layer
   int Gl;       // workgroups per layer for tile-pair kernels
   int Gm;       // workgroups per layer for the mask kernel
+  int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
   int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
   int dbg;      // timing experiments only (env VMR_DEBUG): 1 = skip per-report math, 2 = skip the scan
@@ -81,11 +82,13 @@ struct vmr_ctx {
   double* par = nullptr;       // parameter block, see P_* offsets
   size_t par_doubles = 0;
   // partials
-  double *slotS1 = nullptr, *slotA = nullptr, *slotP = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
+  double *slotA = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
+  double* Hg = nullptr;        // sufficient statistics H[L][Y][Mp][K]
+  bool h_valid = false;        // H matches the current rho
+  unsigned* xmax = nullptr;
   double* elbo_dev = nullptr;  // [0] elbo
   double* lutg = nullptr;      // wide masks (W > 4): the nibble LUT of E[theta] lives in global memory [L][W*256]
   bool have_priors = false, have_state = false;
-  bool slotR_dirty = false;
   bool serial = false;
   int ncu = 256;
   std::vector<std::pair<const void*, int>> occ;   // kernel -> resident workgroups per CU   // a rho sub-step left an unconsumed nu partial in slotR
@@ -362,124 +365,133 @@ struct NoAcc {
 
 #define QCAP 6   // a lane queues at most this many non-zero dwords; larger shares are "heavy"
 
-// Visit the non-zero counts of the tile rows owned by one wave.  Lane (tau, s) owns the 16-B chunks
-// {s, s+S, ..} of row tau.
-//   phase 1 (no divergence): one flag per DWORD of the lane's chunks (v_min_u32 + v_lshl_or);
-//   phase 2: the flags of all 64 lanes are compacted into a wave-local LDS queue of (lane, dword) entries
-//            (ballot/mbcnt prefix sums), so that the per-report arithmetic runs with every lane busy --
-//            without it a wave runs max-over-lanes(non-zeros) trips at ~30 % lane utilisation;
-//   heavy shares (a true tie is reported by most reporters: ~100 non-zeros in a row whose neighbours have
-//            2-5): not queued; all lanes take one dword each, sums come back through a wave reduction.
-// f(tau_e, m, x, acc) handles one report of tie slot tau_e; commit(tau_e, acc) adds acc to that tie's sums.
-// Must be called by every lane of the wave (act = false for lanes without a tie).
-template <class TieAcc, class F, class C>
-__device__ __forceinline__ void scan_tile(const unsigned char* xt, const Geo& g, int tau, int s, bool act,
-                                          unsigned short* wq, F&& f, C&& commit) {
-  const int S = g.S, nchunk = g.nchunk;
-  const unsigned char* row = xt + tau * g.stride;
-  if ((nchunk + S - 1) / S > 12) {   // huge M (b = 1): plain chunk-by-chunk walk
-    if (!act) return;
-    TieAcc a;
-    a.zero();
-    for (int c = s; c < nchunk; c += S) {
-      unsigned nzm = nz_flags16<0>(*reinterpret_cast<const uint4*>(row + c * 16));
-      while (nzm) {
-        int bit = __builtin_ctz(nzm), ch, by;
-        nzm &= nzm - 1;
-        flag_pos(bit, ch, by);
-        f(tau, c * 16 + by, (unsigned)row[c * 16 + by], a);
+// The non-zero counts of the tile rows owned by one wave.  Lane (tau, s) owns the 16-B chunks {s, s+S, ..}
+// of row tau.
+//   build(): phase 1 (no divergence): one flag per DWORD of the lane's chunks (v_min_u32 + v_lshl_or); then the
+//            flags of all 64 lanes are compacted into a wave-local LDS queue of (lane, dword) entries
+//            (ballot/mbcnt prefix sums) -- without it a wave runs max-over-lanes(non-zeros) trips at ~30 % lane
+//            utilisation.  Heavy shares (a true tie is reported by most reporters: ~100 non-zeros in a row whose
+//            neighbours have 2-5) are not queued.
+//   walk():  every lane takes queue entries; f(tau_e, m, x, acc) handles one report of tie slot tau_e,
+//            commit(tau_e, acc) adds acc to that tie's sums.  Heavy shares: all lanes take one dword each, sums
+//            come back through a wave reduction.  walk() may be called several times per build().
+// Both must be called by every lane of the wave (act = false for lanes without a tie).
+struct TileScan {
+  unsigned lo, hi, tot;
+  bool heavy, simple;
+
+  __device__ __forceinline__ void build(const unsigned char* xt, const Geo& g, int tau, int s, bool act,
+                                        unsigned short* wq) {
+    const int S = g.S, nchunk = g.nchunk;
+    const unsigned char* row = xt + tau * g.stride;
+    lo = 0; hi = 0; tot = 0; heavy = false;
+    simple = (nchunk + S - 1) / S > 12;   // huge M (b = 1): plain chunk-by-chunk walk, nothing to build
+    if (simple) return;
+    // phase 1: bit 4*j + i <-> dword i of chunk s + j*S   (lo: chunks 0..7, hi: chunks 8..11)
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        if (j * S < nchunk) {   // wave-uniform
+          const int c = s + j * S;
+          const int cl = c < nchunk ? c : nchunk - 1;
+          const uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
+          unsigned f4 = min(v.x, 1u) | (min(v.y, 1u) << 1) | (min(v.z, 1u) << 2) | (min(v.w, 1u) << 3);
+          f4 = c < nchunk ? f4 : 0u;
+          if (j < 8) lo |= f4 << (4 * j); else hi |= f4 << (4 * (j - 8));
+        }
       }
     }
-    commit(tau, a);
-    return;
-  }
-  // phase 1: bit 4*j + i <-> dword i of chunk s + j*S   (lo: chunks 0..7, hi: chunks 8..11)
-  unsigned lo = 0, hi = 0;
-  if (act) {
+    const int cnt = __popc(lo) + __popc(hi);   // non-zero dwords of the share
+    if (g.dbg & 4) { lo = (cnt == 0x7fffffff) ? 1u : 0u; hi = 0; return; }   // timing experiment: phase 1 only
+    const int lane = threadIdx.x & 63;
+    heavy = cnt > QCAP;
+    const unsigned cl_ = heavy ? 0u : (unsigned)cnt;   // 0..QCAP (< 8)
+    unsigned pre = 0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      if (j * S < nchunk) {   // wave-uniform
-        const int c = s + j * S;
-        const int cl = c < nchunk ? c : nchunk - 1;
-        const uint4 v = *reinterpret_cast<const uint4*>(row + cl * 16);
-        unsigned f4 = min(v.x, 1u) | (min(v.y, 1u) << 1) | (min(v.z, 1u) << 2) | (min(v.w, 1u) << 3);
-        f4 = c < nchunk ? f4 : 0u;
-        if (j < 8) lo |= f4 << (4 * j); else hi |= f4 << (4 * (j - 8));
+    for (int b = 0; b < 3; ++b) {
+      const uint64_t bal = __ballot((cl_ >> b) & 1u);
+      pre += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
+      tot += (unsigned)__popcll(bal) << b;
+    }
+    if (!heavy) {
+      unsigned l2 = lo, h2 = hi, j = pre;
+      while (l2 | h2) {
+        int p;
+        if (l2) { p = __builtin_ctz(l2); l2 &= l2 - 1; } else { p = 32 + __builtin_ctz(h2); h2 &= h2 - 1; }
+        wq[j++] = (unsigned short)((lane << 6) | p);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
-  const int cnt = __popc(lo) + __popc(hi);   // non-zero dwords of the share
-  if (g.dbg & 4) {   // timing experiment: phase 1 only (the impossible count keeps the flags alive)
-    TieAcc a;
-    a.zero();
-    if (cnt == 0x7fffffff) { f(tau, 0, 0u, a); commit(tau, a); }
-    return;
-  }
-  const int lane = threadIdx.x & 63;
-  const int wave_base = threadIdx.x & ~63;
-  const bool heavy = cnt > QCAP;
-  // ---- compaction of the light shares
-  const unsigned cl_ = heavy ? 0u : (unsigned)cnt;   // 0..QCAP (< 8)
-  unsigned pre = 0, tot = 0;
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    const uint64_t bal = __ballot((cl_ >> b) & 1u);
-    pre += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
-    tot += (unsigned)__popcll(bal) << b;
-  }
-  if (!heavy) {
-    unsigned l2 = lo, h2 = hi, j = pre;
-    while (l2 | h2) {
-      int p;
-      if (l2) { p = __builtin_ctz(l2); l2 &= l2 - 1; } else { p = 32 + __builtin_ctz(h2); h2 &= h2 - 1; }
-      wq[j++] = (unsigned short)((lane << 6) | p);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (unsigned e0 = 0; e0 < tot; e0 += 64) {   // wave-uniform trip count
-    const unsigned e = e0 + lane;
-    if (e < tot) {
-      const unsigned ent = wq[e];
-      const int ls = ent >> 6, p = ent & 63;
-      const int tau_e = (wave_base | ls) >> g.lS, s_e = ls & (S - 1);
-      const int off = (s_e + (p >> 2) * S) * 16 + (p & 3) * 4;
-      unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_e * g.stride + off);
+
+  template <class TieAcc, class F, class C>
+  __device__ __forceinline__ void walk(const unsigned char* xt, const Geo& g, int tau, int s, bool act,
+                                       const unsigned short* wq, F&& f, C&& commit) const {
+    const int S = g.S, nchunk = g.nchunk;
+    if (simple) {
+      if (!act) return;
+      const unsigned char* row = xt + tau * g.stride;
       TieAcc a;
       a.zero();
-      while (d) {
-        const int sh = __builtin_ctz(d) & ~7;
-        const unsigned x = (d >> sh) & 0xffu;
-        d &= ~(0xffu << sh);
-        f(tau_e, off + (sh >> 3), x, a);
+      for (int c = s; c < nchunk; c += S) {
+        unsigned nzm = nz_flags16<0>(*reinterpret_cast<const uint4*>(row + c * 16));
+        while (nzm) {
+          int bit = __builtin_ctz(nzm), ch, by;
+          nzm &= nzm - 1;
+          flag_pos(bit, ch, by);
+          f(tau, c * 16 + by, (unsigned)row[c * 16 + by], a);
+        }
       }
-      commit(tau_e, a);
+      commit(tau, a);
+      return;
     }
-  }
-  __builtin_amdgcn_wave_barrier();
-  // ---- heavy shares: lane p < 48 takes dword p of the share
-  uint64_t hm = __ballot(heavy);
-  while (hm) {
-    const int h = __builtin_ctzll(hm);
-    hm &= hm - 1;
-    const int tau_h = (wave_base | h) >> g.lS, s_h = h & (S - 1);
-    const unsigned lo_h = __builtin_amdgcn_readlane((int)lo, h), hi_h = __builtin_amdgcn_readlane((int)hi, h);
-    TieAcc a;
-    a.zero();
-    const bool mine = lane < 32 ? ((lo_h >> lane) & 1u) : (lane < 48 ? ((hi_h >> (lane - 32)) & 1u) : false);
-    if (mine) {
-      const int off = (s_h + (lane >> 2) * S) * 16 + (lane & 3) * 4;
-      unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_h * g.stride + off);
-      while (d) {
-        const int sh = __builtin_ctz(d) & ~7;
-        const unsigned x = (d >> sh) & 0xffu;
-        d &= ~(0xffu << sh);
-        f(tau_h, off + (sh >> 3), x, a);
+    const int lane = threadIdx.x & 63;
+    const int wave_base = threadIdx.x & ~63;
+    for (unsigned e0 = 0; e0 < tot; e0 += 64) {   // wave-uniform trip count
+      const unsigned e = e0 + lane;
+      if (e < tot) {
+        const unsigned ent = wq[e];
+        const int ls = ent >> 6, p = ent & 63;
+        const int tau_e = (wave_base | ls) >> g.lS, s_e = ls & (S - 1);
+        const int off = (s_e + (p >> 2) * S) * 16 + (p & 3) * 4;
+        unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_e * g.stride + off);
+        TieAcc a;
+        a.zero();
+        while (d) {
+          const int sh = __builtin_ctz(d) & ~7;
+          const unsigned x = (d >> sh) & 0xffu;
+          d &= ~(0xffu << sh);
+          f(tau_e, off + (sh >> 3), x, a);
+        }
+        commit(tau_e, a);
       }
     }
-    a.wave_reduce();
-    if (lane == 0) commit(tau_h, a);
+    // heavy shares: lane p < 48 takes dword p of the share
+    uint64_t hm = __ballot(heavy);
+    while (hm) {
+      const int h = __builtin_ctzll(hm);
+      hm &= hm - 1;
+      const int tau_h = (wave_base | h) >> g.lS, s_h = h & (S - 1);
+      const unsigned lo_h = __builtin_amdgcn_readlane((int)lo, h), hi_h = __builtin_amdgcn_readlane((int)hi, h);
+      TieAcc a;
+      a.zero();
+      const bool mine = lane < 32 ? ((lo_h >> lane) & 1u) : (lane < 48 ? ((hi_h >> (lane - 32)) & 1u) : false);
+      if (mine) {
+        const int off = (s_h + (lane >> 2) * S) * 16 + (lane & 3) * 4;
+        unsigned d = *reinterpret_cast<const unsigned*>(xt + tau_h * g.stride + off);
+        while (d) {
+          const int sh = __builtin_ctz(d) & ~7;
+          const unsigned x = (d >> sh) & 0xffu;
+          d &= ~(0xffu << sh);
+          f(tau_h, off + (sh >> 3), x, a);
+        }
+      }
+      a.wave_reduce();
+      if (lane == 0) commit(tau_h, a);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-}
+};
 
 // ------------------------------------------------------------------------------------------
 // set-up kernels
@@ -512,8 +524,9 @@ __global__ void k_pack_r(const uint8_t* __restrict__ src, uint64_t* __restrict__
 
 // coverage flag per tie + sum(X)
 __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restrict__ Rb, uint8_t* __restrict__ cov,
-                        unsigned long long* sumx, size_t rows, int Mp, int W) {
+                        unsigned long long* sumx, unsigned* xmax, size_t rows, int Mp, int W) {
   unsigned long long local = 0;
+  unsigned lmax = 0;
   for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
     bool anyx = false, anyr = false;
     const uint4* p = reinterpret_cast<const uint4*>(X + r * Mp);
@@ -522,14 +535,17 @@ __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restric
       if (v.x | v.y | v.z | v.w) {
         anyx = true;
         unsigned d[4] = {v.x, v.y, v.z, v.w};
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
           local += (d[u] & 0xff) + ((d[u] >> 8) & 0xff) + ((d[u] >> 16) & 0xff) + (d[u] >> 24);
+          lmax = max(lmax, max(max(d[u] & 0xff, (d[u] >> 8) & 0xff), max((d[u] >> 16) & 0xff, d[u] >> 24)));
+        }
       }
     }
     for (int w = 0; w < W; ++w) anyr |= Rb[r * W + w] != 0;
     cov[r] = (anyx && anyr) ? 1 : 0;
   }
   if (local) atomicAdd(sumx, local);
+  if (lmax) atomicMax(xmax, lmax);
 }
 
 __global__ void k_init_rho(const double* __restrict__ pr, double* __restrict__ rho, double* __restrict__ logpr,
@@ -691,14 +707,20 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// gamma, counts half (model.py:698-703, 832-859):
-//   S1[l,m] = sum_{ij: x>0} x * sum_k rho_k w1_k        (gamma_shp - alpha)
-//   mutuality off also P[l,k] = sum x rho_k               (phi_shp - alpha, model.py:861-887)
-// Outputs accumulate into slots (slotS1[l][slot][m], slotP[l][slot][k]).
+// Sufficient statistics of the reports:  H[l,y,m,k] = sum over ties t of x * rho_k(t), taken over the non-zero
+// counts x = X[l,t,m] whose mirrored count X^T[l,t,m] equals y (y = 0 always when mutuality is off).
+// Everything the gamma, phi and nu updates need from X is linear in rho with weights that depend on (m, y, k) only:
+//   gamma_shp[l,m] = alpha + sum_{y,k} w1_k(m,y) H    (model.py:698-703, 832-859; w1 with the OLD parameters)
+//   phi_shp[l,k]   = alpha + sum_{m,y} w1_k(m,y) H    (model.py:731-733, 861-887; w1 with the NEW E[log theta])
+//   nu_shp         = alpha + sum_{l,m,y>0,k} w2_k(m,y) H   (model.py:822-825; H of the NEW rho)
+// so one pass over X per sweep (the rho pass, which rebuilds H from the new rho) replaces three.  H is tiny
+// ([L][Y][Mp][K] doubles, Y = max count + 1); mirror counts 0..HC-1 are accumulated in LDS, the rest with global
+// f64 atomics.  k_hist builds H from the current rho (start of a fit, sub-step tests).
 // ------------------------------------------------------------------------------------------
-struct CountArgs {
-  const uint8_t* X; const double* rho; const double* par;
-  double* slotS1; double* slotP;
+#define HC 3   // mirror-count levels cached in LDS (93 % of the reports at BASELINE config 3)
+
+struct HistArgs {
+  const uint8_t* X; const double* rho; double* Hg;
   int Gl;   // workgroups per layer of this launch
 };
 
@@ -737,29 +759,39 @@ struct TileIter {
   }
 };
 
-#define QBYTES (TPB / 64 * 64 * QCAP * 2)   // the four wave-local queues of a workgroup
+// one report into H: LDS cache for small mirror counts, global atomics beyond
+template <int K>
+__device__ __forceinline__ void hist_add(double* Hc, double* Hl /*layer's [Y][Mp][K]*/, int Mp, int m, unsigned y,
+                                         double dx, const double* r) {
+  if (y < HC) {
+    double* d = Hc + ((size_t)y * Mp + m) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) atomicAdd(&d[k], dx * r[k]);
+  } else {
+    double* d = Hl + ((size_t)y * Mp + m) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) atomicAdd(&d[k], dx * r[k]);
+  }
+}
+__device__ __forceinline__ void hist_flush(const double* Hc, double* Hl, int n) {
+  for (int q = threadIdx.x; q < n; q += TPB) {
+    const double v = Hc[q];
+    if (v != 0.0) atomicAdd(&Hl[q], v);
+  }
+}
 
 template <int K, bool MUT, int PF>
-__global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_gamma_counts(CountArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_hist(HistArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
-  double* S1 = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
-  double* red = S1 + g.Mp;
-  double* rt = red + 8;                        // rho of the pair's ties [nt][K]
-  double* ct = rt + (size_t)g.nt * K;          // weight table [Mp][K] (mutuality)
-  unsigned short* wq = reinterpret_cast<unsigned short*>(ct + (MUT ? (size_t)g.Mp * K : 0)) + (threadIdx.x >> 6) * (64 * QCAP);
-  const ParOff o = par_off(g.L, g.Mp, g.K);
+  double* rt = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);   // rho of the pair's ties [nt][K]
+  double* Hc = rt + (size_t)g.nt * K;                                        // [HC][Mp][K]
+  const int nHc = (MUT ? HC : 1) * g.Mp * K;
+  unsigned short* wq = reinterpret_cast<unsigned short*>(Hc + nHc) + (threadIdx.x >> 6) * (64 * QCAP);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
-  for (int m = threadIdx.x; m < g.Mp; m += TPB) S1[m] = 0.0;
-  double Gla[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
-  const double gnu = a.par[o.sc + SC_G_NU];
-  SumK<K> Pk;
-  Pk.zero();
-  if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
-
+  for (int q = threadIdx.x; q < nHc; q += TPB) Hc[q] = 0.0;
+  double* Hl = a.Hg + (size_t)l * g.Y * g.Mp * K;
   TileIter it;
   it.init(g, p0);
   const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
@@ -788,138 +820,47 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_gamma_counts(CountArgs a
     __syncthreads();
     it.next();
     if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }   // flies while this pair is scanned
-    if (!(g.dbg & 2)) {
-      scan_tile<NoAcc>(xt, g, tau, s, act, wq,
-        [&](int te, int m, unsigned x, NoAcc&) {
-          if (g.dbg & 1) { Pk.v[0] += (double)x; return; }
-          const double dx = (double)x;
-          const double* r = rt + te * K;
-          double sum = 0.0;
-          if (MUT) {
-            double w[K], cy[K];
-            weights<K>(w, cy, ct, m, (unsigned)xt[cur.mirror(te) * g.stride + m]);
-#pragma unroll
-            for (int k = 0; k < K; ++k) sum += r[k] * w[k];
-          } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) { sum += r[k]; Pk.v[k] += dx * r[k]; }
-          }
-          atomicAdd(&S1[m], dx * sum);
-        },
-        [&](int, const NoAcc&) {});
-    }
+    TileScan sc;
+    sc.build(xt, g, tau, s, act, wq);
+    sc.walk<NoAcc>(xt, g, tau, s, act, wq,
+      [&](int te, int m, unsigned x, NoAcc&) {
+        const unsigned y = MUT ? (unsigned)xt[cur.mirror(te) * g.stride + m] : 0u;
+        hist_add<K>(Hc, Hl, g.Mp, m, y, (double)x, rt + te * K);
+      },
+      [&](int, const NoAcc&) {});
     __syncthreads();
   }
-  double* oS = a.slotS1 + ((size_t)l * NSLOT + (gb % NSLOT)) * g.Mp;
-  for (int m = threadIdx.x; m < g.M; m += TPB) atomicAdd(&oS[m], S1[m]);
-  if (!MUT || g.dbg) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      double v = block_sum(Pk.v[k], red);
-      if (threadIdx.x == 0 && !MUT) atomicAdd(&a.slotP[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
-    }
-  }
+  hist_flush(Hc, Hl, nHc);
 }
 
 // ------------------------------------------------------------------------------------------
-// phi, counts (mutuality on; model.py:731-733, 861-887): P[l,k] = sum x rho_k w1_k with the
-// NEW E[log theta] -- the cache refresh of model.py:647 sits between the two updates.
-// ------------------------------------------------------------------------------------------
-template <int K, int PF>
-__global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_phi(CountArgs a, Geo g) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  unsigned char* xt = smem;
-  double* red = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);
-  double* rt = red + 8;
-  double* ct = rt + (size_t)g.nt * K;
-  unsigned short* wq = reinterpret_cast<unsigned short*>(ct + (size_t)g.Mp * K) + (threadIdx.x >> 6) * (64 * QCAP);
-  const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
-  const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
-  double Gla[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) Gla[k] = a.par[o.G_la + l * K + k];
-  const double gnu = a.par[o.sc + SC_G_NU];
-  SumK<K> Pk;
-  Pk.zero();
-  build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
-  TileIter it;
-  it.init(g, p0);
-  const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
-  const uint8_t* Xl = a.X + (size_t)l * g.N * g.N * g.Mp;
-  const double* rl = a.rho + (size_t)l * g.N * g.N * K;
-  TileStream<PF> ts;
-  ts.init(g);
-  double rn[K];
-  auto fetch_rho = [&]() {
-    int i, j;
-    const bool ok = it.coords(tau, i, j);
-#pragma unroll
-    for (int k = 0; k < K; ++k) rn[k] = ok ? rl[((size_t)i * g.N + j) * K + k] : 0.0;
-  };
-  if (p0 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
-  __syncthreads();
-  for (long long p = p0; p < p1; ++p) {
-    ts.store(xt);
-    int i, j;
-    const bool act = it.coords(tau, i, j);
-    if (s == 0 && tau < g.nt) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) rt[tau * K + k] = rn[k];
-    }
-    const TileIter cur = it;
-    __syncthreads();
-    it.next();
-    if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); fetch_rho(); }
-    if (!(g.dbg & 2)) {
-      scan_tile<NoAcc>(xt, g, tau, s, act, wq,
-        [&](int te, int m, unsigned x, NoAcc&) {
-          if (g.dbg & 1) { Pk.v[0] += (double)x; return; }
-          const double dx = (double)x;
-          const double* r = rt + te * K;
-          double w[K], cy[K];
-          weights<K>(w, cy, ct, m, (unsigned)xt[cur.mirror(te) * g.stride + m]);
-#pragma unroll
-          for (int k = 0; k < K; ++k) Pk.v[k] += dx * r[k] * w[k];
-        },
-        [&](int, const NoAcc&) {});
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double v = block_sum(Pk.v[k], red);
-    if (threadIdx.x == 0) atomicAdd(&a.slotP[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// rho (+ nu partial, + ELBO data terms)   model.py:763-830, 889-923, 948-995, 1013
-// slotR[slot][4]: [0] nu partial, [1] ELBO linear+entropy terms, [2] ELBO log terms,
+// rho (+ H of the new rho, + ELBO data terms)   model.py:763-818, 889-923; ELBO :948-995, :1013
+// slotR[slot][4]: [1] ELBO linear+entropy terms, [2] ELBO log terms,
 //                 [3] sum_t (sum_k rho_k) Q_t  (multiplied by -E[nu] in k_fin_rho)
-// One scan of the tile serves rho AND nu: per tie V_k = sum_{reports with a mirror count} x w2_k
-// is collected next to U_k, and sum_k rho_new_k V_k is the tie's share of nu_shp (model.py:822-825).
+// Walk 1 over the pair's non-zero counts collects U_k per tie; after the per-tie update the same queue is
+// walked again with the NEW rho to rebuild H (and, on ELBO sweeps, the log terms and the mirror sums Q).
 // ------------------------------------------------------------------------------------------
 struct RhoArgs {
   const uint8_t* X; const uint64_t* Rb; double* rho; const double* logpr; const double* par;
   double* slotR;
-  const double* lutg;   // global nibble LUT when W > 4, else NULL (LUT built in LDS)
+  const double* lutg;   // nibble LUT of E[theta], [L][W*256]
+  double* Hg;
   int Gl;
 };
 
 template <int K>
-struct SumUV {
-  double U[K], V[K];
+struct SumU {
+  double U[K];
   __device__ __forceinline__ void zero() {
 #pragma unroll
-    for (int k = 0; k < K; ++k) { U[k] = 0.0; V[k] = 0.0; }
+    for (int k = 0; k < K; ++k) U[k] = 0.0;
   }
   __device__ __forceinline__ void wave_reduce() {
 #pragma unroll
-    for (int k = 0; k < K; ++k) { U[k] = wave_sum(U[k]); V[k] = wave_sum(V[k]); }
+    for (int k = 0; k < K; ++k) U[k] = wave_sum(U[k]);
   }
 };
-struct SumQ {   // ELBO scan: the mirror tie's masked count
+struct SumQ {   // ELBO walk: the mirror tie's masked count
   unsigned q;
   __device__ __forceinline__ void zero() { q = 0u; }
   __device__ __forceinline__ void wave_reduce() {
@@ -934,42 +875,33 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   unsigned char* xt = smem;
   size_t off = (size_t)g.nt * g.stride;
   uint64_t* rw = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)g.nt * g.W * 8;
-  const bool lut_lds = (a.lutg == nullptr);
-  double* lut_s = reinterpret_cast<double*>(smem + off); off += lut_lds ? (size_t)g.W * 16 * 16 * 8 : 0;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
   double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
-  // per tie: U[K], V[K] during the update scan; afterwards (ELBO scan) the same bytes hold exp(rho)[K] and Q
-  double* uv = reinterpret_cast<double*>(smem + off);
-  double* ert = uv;
-  unsigned* qs = reinterpret_cast<unsigned*>(uv + (size_t)g.nt * K);
-  off += (size_t)g.nt * 2 * K * 8;
+  double* ut = reinterpret_cast<double*>(smem + off); off += (size_t)g.nt * K * 8;    // U per tie; exp(rho) in the ELBO walk
+  double* rt = reinterpret_cast<double*>(smem + off); off += (size_t)g.nt * K * 8;    // (new) rho per tie
+  const int nHc = UPDATE ? (MUT ? HC : 1) * g.Mp * K : 0;
+  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;
   double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
+  unsigned* qs = reinterpret_cast<unsigned*>(smem + off); off += ELBO ? (size_t)g.nt * 4 : 0;
   unsigned short* wq = reinterpret_cast<unsigned short*>(smem + off) + (threadIdx.x >> 6) * (64 * QCAP);
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
-  const double* Eth = a.par + o.E_th + (size_t)l * g.Mp;
   for (int m = threadIdx.x; m < g.Mp; m += TPB) {
     lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
     if (ELBO) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
   }
-  // nibble LUT: lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3 (LDS, or global for
-  // wide masks); wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
-  if (lut_lds) {
-    for (int q = threadIdx.x; q < g.W * 16 * 16; q += TPB) {
-      int n = q >> 4, e = q & 15;
-      double v = 0.0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int m = n * 4 + u;
-        if ((e >> u) & 1) v += (m < g.Mp) ? Eth[m] : 0.0;
-      }
-      lut_s[q] = v;
-    }
+  for (int q = threadIdx.x; q < nHc; q += TPB) Hc[q] = 0.0;
+  // lut[n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3 (global, L1/L2 resident);
+  // wsum[w] = sum over the 64 reporters of word w (shortcut for all-ones words)
+  const double* lut = a.lutg + (size_t)l * g.W * 256;
+  for (int w = threadIdx.x; w < g.W; w += TPB) {
+    double v = 0.0;
+    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
+    wsum[w] = v;
   }
-  const double* lut = lut_lds ? lut_s : a.lutg + (size_t)l * g.W * 256;
   double Ela[K], lla[K], Gla[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -978,14 +910,9 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
   // UPDATE: the weights use the current G_nu; stand-alone ELBO: the stale one (model.py:970)
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];
   const double eps = g.eps;
-  double nu_acc = 0.0, e_lin = 0.0, e_q = 0.0, e_log = 0.0;
-  __syncthreads();
-  for (int w = threadIdx.x; w < g.W; w += TPB) {
-    double v = 0.0;
-    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
-    wsum[w] = v;
-  }
+  double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
+  double* Hl = a.Hg + (size_t)l * g.Y * g.Mp * K;
 
   TileIter it;
   it.init(g, p0);
@@ -1025,7 +952,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
     if (UPDATE && s == 0 && tau < g.nt) {
 #pragma unroll
-      for (int k = 0; k < 2 * K; ++k) uv[tau * 2 * K + k] = 0.0;
+      for (int k = 0; k < K; ++k) ut[tau * K + k] = 0.0;
     }
     __syncthreads();
     it.next();
@@ -1041,40 +968,30 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
       }
     }
     Tt = group_sum(Tt, g.S);
+    TileScan sc;
+    sc.build(xt, g, tau, s, act, wq);
     if (UPDATE) {
-      if (!(g.dbg & 2)) {
-        scan_tile<SumUV<K>>(xt, g, tau, s, act, wq,
-          [&](int te, int m, unsigned x, SumUV<K>& acc) {
-            if (g.dbg & 1) { acc.U[0] += (double)x; return; }
-            const double dx = (double)x, lt = lth[m];
-            if (MUT) {
-              const unsigned y = xt[cur.mirror(te) * g.stride + m];
-              double w[K], cy[K];
-              weights<K>(w, cy, ct, m, y);
+      sc.walk<SumU<K>>(xt, g, tau, s, act, wq,
+        [&](int te, int m, unsigned x, SumU<K>& acc) {
+          const double dx = (double)x, lt = lth[m];
+          if (MUT) {
+            double w[K], cy[K];
+            weights<K>(w, cy, ct, m, (unsigned)xt[cur.mirror(te) * g.stride + m]);
 #pragma unroll
-              for (int k = 0; k < K; ++k) {
-                acc.U[k] += (lt + lla[k]) * (dx * w[k]);
-                acc.V[k] += (y != 0) ? dx * (cy[k] * w[k]) : 0.0;   // x w2_k, model.py:694-696
-              }
-            } else {
+            for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * (dx * w[k]);
+          } else {
 #pragma unroll
-              for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * dx;
-            }
-          },
-          [&](int te, const SumUV<K>& t) {   // the tie's sums live in LDS; a tie belongs to one wave
-            double* d = uv + te * 2 * K;
+            for (int k = 0; k < K; ++k) acc.U[k] += (lt + lla[k]) * dx;
+          }
+        },
+        [&](int te, const SumU<K>& t) {   // the tie's sums live in LDS; a tie belongs to one wave
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              atomicAdd(&d[k], t.U[k]);
-              if (MUT && t.V[k] != 0.0) atomicAdd(&d[K + k], t.V[k]);   // only reports with a mirror count feed nu
-            }
-          });
-        __builtin_amdgcn_wave_barrier();
-      }
+          for (int k = 0; k < K; ++k) atomicAdd(&ut[te * K + k], t.U[k]);
+        });
       double sum = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const double u = (tau < g.nt) ? uv[tau * 2 * K + k] : 0.0;
+        const double u = (tau < g.nt) ? ut[tau * K + k] : 0.0;
         r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
         sum += r[k];
       }
@@ -1084,39 +1001,42 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
       }
       if (act && s == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          rl[tg * K + k] = r[k];
-          if (MUT) nu_acc += uv[tau * 2 * K + K + k] * r[k];   // the tie's share of model.py:822-825
-        }
+        for (int k = 0; k < K; ++k) rl[tg * K + k] = r[k];
       }
     }
-    if (ELBO) {
-      if (UPDATE) __syncthreads();   // every wave is done with U,V before the bytes are reused
-      if (s == 0 && tau < g.nt) {
+    if (s == 0 && tau < g.nt) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) ert[tau * K + k] = exp(r[k]);   // exp(rho), model.py:971
-        qs[tau] = 0u;
+      for (int k = 0; k < K; ++k) {
+        rt[tau * K + k] = r[k];
+        if (ELBO) ut[tau * K + k] = exp(r[k]);   // exp(rho), model.py:971 (U is consumed)
       }
-      __syncthreads();
-      scan_tile<SumQ>(xt, g, tau, s, act, wq,
-        [&](int te, int m, unsigned x, SumQ& acc) {
-          const double dx = (double)x;
-          const int mt = cur.mirror(te);
-          const unsigned y = MUT ? (unsigned)xt[mt * g.stride + m] : 0u;
+      if (ELBO) qs[tau] = 0u;
+    }
+    if (ELBO) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // Q crosses waves, the rest is wave-local
+    // walk 2: H of the new rho; ELBO log terms and mirror sums
+    sc.walk<SumQ>(xt, g, tau, s, act, wq,
+      [&](int te, int m, unsigned x, SumQ& acc) {
+        const double dx = (double)x;
+        const int mt = cur.mirror(te);
+        const unsigned y = MUT ? (unsigned)xt[mt * g.stride + m] : 0u;
+        if (UPDATE) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + te * K);
+        if (ELBO) {
           const bool in_r = (rw[te * g.W + (m >> 6)] >> (m & 63)) & 1ull;
           double inner = 0.0;
           if (in_r) {
             const double z2 = gnu * (double)y, gt = Gth[m];
-            const double* er = ert + te * K;
+            const double* er = ut + te * K;
 #pragma unroll
             for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
           }
           e_log += dx * log(inner + eps);
           if (MUT && ((rw[mt * g.W + (m >> 6)] >> (m & 63)) & 1ull)) acc.q += x;   // R[mirror] X^T[mirror]
-        },
-        [&](int te, const SumQ& t) {   // Q of the MIRROR tie: sum_m R[mirror,m] X[this,m]; the mirror may belong to another wave
-          if (t.q) atomicAdd(&qs[cur.mirror(te)], t.q);
-        });
+        }
+      },
+      [&](int te, const SumQ& t) {   // Q of the MIRROR tie: sum_m R[mirror,m] X[this,m]
+        if (ELBO && t.q) atomicAdd(&qs[cur.mirror(te)], t.q);
+      });
+    if (ELBO) {
       __syncthreads();
       if (act && s == 0) {
         double sr = 0.0, se = 0.0, ent = 0.0;
@@ -1131,48 +1051,57 @@ __global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
     }
     __syncthreads();
   }
-  double v0 = block_sum(nu_acc, red);
-  double v1 = block_sum(e_lin, red);
-  double v2 = block_sum(e_log, red);
-  double v3 = block_sum(e_q, red);
-  if (threadIdx.x == 0) {
-    double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
-    if (UPDATE && MUT) atomicAdd(&out[0], v0);
-    if (ELBO) { atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3); }
+  if (UPDATE) hist_flush(Hc, Hl, nHc);
+  if (ELBO) {
+    double v1 = block_sum(e_lin, red);
+    double v2 = block_sum(e_log, red);
+    double v3 = block_sum(e_q, red);
+    if (threadIdx.x == 0) {
+      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // finalize kernels (one workgroup per layer / one workgroup)
 // ------------------------------------------------------------------------------------------
-// gamma_shp/rte (model.py:700-718), then phi_rte from the same A with the new E[theta]
-// (model.py:742-749); mutuality off: phi_shp too, and commit phi.
-__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, double* slotS1, double* slotA, double* slotP, Geo g) {
+// gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
+// then phi_rte from the same A with the new E[theta] (model.py:742-749); mutuality off: phi_shp too.
+__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA, Geo g) {
   __shared__ double red[8];
-  __shared__ double ela_old[KMAX];
+  __shared__ double ela_old[KMAX], gla_old[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K, Wp = g.W * 64;
-  if (threadIdx.x < K) ela_old[threadIdx.x] = par[o.p_shp + l * K + threadIdx.x] / par[o.p_rte + l * K + threadIdx.x];
+  if (threadIdx.x < K) {
+    ela_old[threadIdx.x] = par[o.p_shp + l * K + threadIdx.x] / par[o.p_rte + l * K + threadIdx.x];
+    gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
+  }
   __syncthreads();
-  double pr[KMAX];
-  for (int k = 0; k < KMAX; ++k) pr[k] = 0.0;
+  const double gnu = par[o.sc + SC_G_NU];
+  const double* Hl = Hg + (size_t)l * g.Y * g.Mp * K;
+  double pr[KMAX], p0[KMAX];
+  for (int k = 0; k < KMAX; ++k) { pr[k] = 0.0; p0[k] = 0.0; }
   for (int m = threadIdx.x; m < g.M; m += TPB) {
+    const size_t q = (size_t)l * g.Mp + m;
+    const double gth = par[o.G_th + q];   // still the old value
     double s1 = 0.0;
-    for (int sl = 0; sl < NSLOT; ++sl) {
-      double* ps = &slotS1[((size_t)l * NSLOT + sl) * g.Mp + m];
-      s1 += *ps; *ps = 0.0;   // consume: the slots are zero again for the next sweep
-    }
+    for (int y = 0; y < g.Y; ++y)
+      for (int k = 0; k < K; ++k) {
+        const double h = Hl[((size_t)y * g.Mp + m) * K + k];
+        s1 += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * h;
+        if (y == 0) p0[k] += h;
+      }
     double A[KMAX], rte = 0.0;
     for (int k = 0; k < K; ++k) {
       double ak = 0.0;
       for (int sl = 0; sl < NSLOT; ++sl) {
         double* pa = &slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];
-        ak += *pa; *pa = 0.0;
+        ak += *pa; *pa = 0.0;   // consume: the slots are zero again for the next sweep
       }
       A[k] = ak;
       rte += ela_old[k] * ak;
     }
-    size_t q = (size_t)l * g.Mp + m;
     double shp = par[o.a_th + q] + s1;
     rte = par[o.b_th + q] + rte;
     par[o.g_shp + q] = shp; par[o.g_rte + q] = rte;
@@ -1182,16 +1111,12 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, double* slotS1, 
   }
   for (int k = 0; k < K; ++k) {
     double v = block_sum(pr[k], red);
+    double ps = g.mut ? 0.0 : block_sum(p0[k], red);   // mutuality off: phi_shp = alpha + sum x rho_k (model.py:861-887)
     if (threadIdx.x == 0) {
       double rte = par[o.b_la + l * K + k] + v;
       if (g.mut) {
         par[o.p_rte_pend + l * K + k] = rte;
       } else {
-        double ps = 0.0;
-        for (int sl = 0; sl < NSLOT; ++sl) {
-          double* pp = &slotP[((size_t)l * NSLOT + sl) * K + k];
-          ps += *pp; *pp = 0.0;
-        }
         double shp = par[o.a_la + l * K + k] + ps;
         par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
         double lg = digamma_pos(shp) - log(rte);
@@ -1201,21 +1126,34 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, double* slotS1, 
   }
 }
 
-// phi commit, mutuality on (model.py:731-749)
-__global__ void k_fin_phi(double* par, double* slotP, Geo g) {
+// phi commit, mutuality on: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887; the cache
+// refresh of :647 sits between the two updates), phi_rte as computed by k_fin_gamma (model.py:742-749)
+__global__ __launch_bounds__(TPB) void k_fin_phi(double* par, const double* __restrict__ Hg, Geo g) {
+  __shared__ double red[8];
+  __shared__ double gla_old[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= g.L * g.K) return;
-  int l = q / g.K, k = q - l * g.K;
-  double ps = 0.0;
-  for (int sl = 0; sl < NSLOT; ++sl) {
-    double* pp = &slotP[((size_t)l * NSLOT + sl) * g.K + k];
-    ps += *pp; *pp = 0.0;
+  const int l = blockIdx.x, K = g.K;
+  if (threadIdx.x < K) gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
+  __syncthreads();
+  const double gnu = par[o.sc + SC_G_NU];
+  const double* Hl = Hg + (size_t)l * g.Y * g.Mp * K;
+  double ps[KMAX];
+  for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
+  for (int m = threadIdx.x; m < g.M; m += TPB) {
+    const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // new
+    for (int y = 0; y < g.Y; ++y)
+      for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * Hl[((size_t)y * g.Mp + m) * K + k];
   }
-  double shp = par[o.a_la + q] + ps, rte = par[o.p_rte_pend + q];
-  par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
-  double lg = digamma_pos(shp) - log(rte);
-  par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+  for (int k = 0; k < K; ++k) {
+    double v = block_sum(ps[k], red);
+    if (threadIdx.x == 0) {
+      const int q = l * K + k;
+      double shp = par[o.a_la + q] + v, rte = par[o.p_rte_pend + q];
+      par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
+      double lg = digamma_pos(shp) - log(rte);
+      par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+    }
+  }
 }
 
 __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double qa, double qb) {
@@ -1223,16 +1161,29 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
   return lgamma(qa) - pa * log(qb) + (pa - qa) * digamma_pos(qa) + qa * (1.0 - pb / qb);
 }
 
-// nu commit (model.py:822-825) and/or ELBO assembly (model.py:997-1013)
-__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* slotR, double* elbo_out, int do_nu, int do_elbo,
-                                                 Geo g) {
+// nu from H of the new rho (model.py:694-696, 822-825: sum x w2_k rho_k) and/or ELBO assembly (model.py:997-1013)
+__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, const double* __restrict__ Hg, double* slotR, double* elbo_out,
+                                                 int do_nu, int do_elbo, Geo g) {
   __shared__ double red[8];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (g.mut) {
+    const double gnu = sc[SC_G_NU];
+    for (int q = threadIdx.x; q < g.L * g.M; q += TPB) {
+      const int l = q / g.M, m = q - l * g.M;
+      const double gth = par[o.G_th + (size_t)l * g.Mp + m];
+      const double* Hl = Hg + (size_t)l * g.Y * g.Mp * g.K;
+      for (int y = 1; y < g.Y; ++y)
+        for (int k = 0; k < g.K; ++k) {
+          const double z1 = gth * par[o.G_la + l * g.K + k], z2 = gnu * (double)y;
+          a0 += (z2 / (z1 + z2)) * Hl[((size_t)y * g.Mp + m) * g.K + k];
+        }
+    }
+  }
   if (threadIdx.x < NSLOT) {
     double* ps = slotR + (size_t)threadIdx.x * 4;
-    a0 = ps[0]; a1 = ps[1]; a2 = ps[2]; a3 = ps[3];
+    a1 = ps[1]; a2 = ps[2]; a3 = ps[3];
     ps[0] = ps[1] = ps[2] = ps[3] = 0.0;   // consume
   }
   a0 = block_sum(a0, red); a1 = block_sum(a1, red); a2 = block_sum(a2, red); a3 = block_sum(a3, red);
@@ -1285,18 +1236,15 @@ static int fail(vmr_handle h, int code, const char* msg) {
 
 static size_t shmem_ct(const Geo& g) { return g.mut ? (size_t)g.Mp * g.K * 8 : 0; }
 static size_t shmem_q() { return (size_t)(TPB / 64) * 64 * QCAP * 2; }
-static size_t shmem_counts(const Geo& g) {
-  return (size_t)g.nt * g.stride + (size_t)g.Mp * 8 + 64 + (size_t)g.nt * g.K * 8 + shmem_ct(g) + shmem_q();
-}
-static size_t shmem_phi(const Geo& g) {
-  return (size_t)g.nt * g.stride + 64 + (size_t)g.nt * g.K * 8 + shmem_ct(g) + shmem_q();
+static size_t shmem_hc(const Geo& g) { return (size_t)(g.mut ? HC : 1) * g.Mp * g.K * 8; }
+static size_t shmem_hist(const Geo& g) {
+  return (size_t)g.nt * g.stride + (size_t)g.nt * g.K * 8 + shmem_hc(g) + shmem_q() + 16;
 }
 static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
-  size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (g.W > 4 ? 0 : (size_t)g.W * 16 * 16 * 8) + (size_t)g.W * 8 +
-             (size_t)g.Mp * 8 + 64 + shmem_ct(g) + shmem_q();
-  n += (size_t)g.nt * 2 * g.K * 8;   // U,V / exp(rho),Q per tie
-  if (elbo) n += (size_t)g.Mp * 8;
-  (void)update;
+  size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 8 + (size_t)g.Mp * 8 + 64 + shmem_ct(g) +
+             2 * (size_t)g.nt * g.K * 8 + shmem_q();
+  if (update) n += shmem_hc(g);
+  if (elbo) n += (size_t)g.Mp * 8 + (size_t)g.nt * 4;
   return n + 16;
 }
 
@@ -1357,12 +1305,36 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
   return VMR_OK;
 }
 
+// H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
+static int launch_hist(vmr_ctx* h) {
+  const Geo& g = h->g;
+  HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * g.Y * g.Mp * g.K * 8, h->stream));
+  {
+    Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
+    HistArgs a{h->X, h->rho, h->Hg, 1};
+    size_t sm = shmem_hist(g);
+    int rc = VMR_OK;
+    if (g.mut) {
+      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_hist<KK, true, PP>, sm, &a.Gl))) return rc;
+                  hipLaunchKernelGGL((k_hist<KK, true, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
+    } else {
+      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_hist<KK, false, PP>, sm, &a.Gl))) return rc;
+                  hipLaunchKernelGGL((k_hist<KK, false, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  h->h_valid = true;
+  return VMR_OK;
+}
+
 static int launch_gamma(vmr_ctx* h) {
   const Geo& g = h->g;
-  // fork: the mask half (memory/latency-bound, few VALU ops) overlaps the counts half (VALU-bound)
-  hipStream_t ms = h->serial ? h->stream : h->stream2;   // VMR_SERIAL=1: no overlap (kernel timing experiments)
-  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(ms, h->ev_fork, 0));
+  // fork: the mask sums A = sum_ij R rho (memory-bound) run beside the statistics pass when one is needed
+  hipStream_t ms = (h->serial || h->h_valid) ? h->stream : h->stream2;
+  if (ms != h->stream) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(ms, h->ev_fork, 0));
+  }
   {
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
@@ -1373,25 +1345,19 @@ static int launch_gamma(vmr_ctx* h) {
       default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
     }
   }
-  HIPCHK(h, hipEventRecord(h->ev_join, ms));
-  {
-    Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
-    CountArgs a{h->X, h->rho, h->par, h->slotS1, h->slotP, 1};
-    size_t sm = shmem_counts(g);
-    int rc = VMR_OK;
-    if (g.mut) {
-      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_gamma_counts<KK, true, PP>, sm, &a.Gl))) return rc;
-                  hipLaunchKernelGGL((k_gamma_counts<KK, true, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
-    } else {
-      DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_gamma_counts<KK, false, PP>, sm, &a.Gl))) return rc;
-                  hipLaunchKernelGGL((k_gamma_counts<KK, false, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
-    }
+  if (ms != h->stream) {
+    HIPCHK(h, hipEventRecord(h->ev_join, ms));
+    int rc = launch_hist(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));   // join
+  } else if (!h->h_valid) {
+    int rc = launch_hist(h);
+    if (rc) return rc;
   }
-  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));   // join
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->slotS1, h->slotA, h->slotP, g);
-    if (h->lutg) hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, g);
+    hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -1400,18 +1366,10 @@ static int launch_gamma(vmr_ctx* h) {
 static int launch_phi(vmr_ctx* h) {
   const Geo& g = h->g;
   if (!g.mut) return VMR_OK;   // committed by k_fin_gamma
-  {
-    Prof p(h, VMR_KERNEL_PHI);
-    CountArgs a{h->X, h->rho, h->par, h->slotS1, h->slotP, 1};
-    size_t sm = shmem_phi(g);
-    int rc = VMR_OK;
-    DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_phi<KK, PP>, sm, &a.Gl))) return rc;
-                hipLaunchKernelGGL((k_phi<KK, PP>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
-  }
+  if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    int n = g.L * g.K;
-    hipLaunchKernelGGL(k_fin_phi, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->par, h->slotP, g);
+    hipLaunchKernelGGL(k_fin_phi, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -1420,13 +1378,11 @@ static int launch_phi(vmr_ctx* h) {
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   const Geo& g = h->g;
-  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, 1};
+  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
-  // the nu sub-step may be skipped by a caller: start from clean slots when nobody consumed them
-  if (h->slotR_dirty) HIPCHK(h, hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
-  h->slotR_dirty = (mode == 0 && !commit_nu);
+  if (mode != 2) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
@@ -1439,9 +1395,10 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     }
 #undef LRHO
   }
+  if (mode != 2) h->h_valid = true;
   if (mode != 0 || commit_nu) {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev,
+    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev,
                        (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0, g);
   }
   HIPCHK(h, hipGetLastError());
@@ -1464,6 +1421,7 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.lS = 0; while ((1 << g.lS) < g.S) ++g.lS;
   g.P = (long long)g.nb * (g.nb + 1) / 2;
   g.Gl = 0;   // per launch, see grid_per_layer()
+  g.Y = 1;    // set by vmr_create once the largest count is known
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
@@ -1520,6 +1478,8 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipMalloc(&h->cov, rows));
   CCHK(hipMalloc(&h->sumx, 8));
   CCHK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
+  CCHK(hipMalloc(&h->xmax, 4));
+  CCHK(hipMemsetAsync(h->xmax, 0, 4, h->stream));
   {
     uint8_t* tmp = nullptr;
     const uint8_t* src = X;
@@ -1530,7 +1490,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     tmp = nullptr; src = R;
     if (R && !data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
     hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
-    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, rows, g.Mp, g.W);
+    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, h->xmax, rows, g.Mp, g.W);
     CCHK(hipStreamSynchronize(h->stream));
     if (tmp) CCHK(hipFree(tmp));
   }
@@ -1541,14 +1501,17 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipMalloc(&h->par, o.total * 8));
   CCHK(hipMemsetAsync(h->par, 0, o.total * 8, h->stream));
   {
-    size_t nS1 = (size_t)L * NSLOT * g.Mp * 8, nA = (size_t)L * NSLOT * g.W * 64 * K * 8, nP = (size_t)L * NSLOT * K * 8;
-    CCHK(hipMalloc(&h->slotS1, nS1)); CCHK(hipMemsetAsync(h->slotS1, 0, nS1, h->stream));
+    size_t nA = (size_t)L * NSLOT * g.W * 64 * K * 8;
     CCHK(hipMalloc(&h->slotA, nA)); CCHK(hipMemsetAsync(h->slotA, 0, nA, h->stream));
-    CCHK(hipMalloc(&h->slotP, nP)); CCHK(hipMemsetAsync(h->slotP, 0, nP, h->stream));
     CCHK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CCHK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
+    unsigned xm = 0;
+    CCHK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
+    g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
+    CCHK(hipMalloc(&h->Hg, (size_t)L * g.Y * g.Mp * K * 8));
+    CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * g.Y * g.Mp * K * 8, h->stream));
   }
   CCHK(hipMalloc(&h->elbo_dev, 8 * 8));
-  if (g.W > 4) CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
+  CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
   CCHK(hipStreamSynchronize(h->stream));
 #undef CCHK
   *out = h;
@@ -1560,7 +1523,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotS1, h->slotA, h->slotP, h->slotR, h->elbo_dev, h->lutg};
+  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1631,10 +1594,11 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   }
   hipLaunchKernelGGL(k_init_rho, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, n, g.eps);
   hipLaunchKernelGGL(k_derive_all, dim3(8), dim3(256), 0, h->stream, h->par, g);
-  if (h->lutg) hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
+  hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
+  h->h_valid = false;
   return VMR_OK;
 }
 
@@ -1690,10 +1654,9 @@ int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;   // rho updated, nu NOT committed
   if (!want_elbo) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev, 0, 0, h->g);
+    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, 0, 0, h->g);
     HIPCHK(h, hipGetLastError());
   }
-  h->slotR_dirty = false;   // consumed by k_fin_rho either way
   double v[4];
   HIPCHK(h, hipMemcpyAsync(v, h->elbo_dev, 32, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1717,13 +1680,13 @@ int vmr_sub_step(vmr_handle h, int which) {
   switch (which) {
     case VMR_STEP_GAMMA: return launch_gamma(h);
     case VMR_STEP_PHI: return launch_phi(h);
-    // rho and nu come out of one pass over X; the nu value is committed by the NU sub-step
+    // the rho pass also rebuilds the statistics H the nu update reads; nu is committed by the NU sub-step
     case VMR_STEP_RHO: return launch_rho(h, 0, false);
     case VMR_STEP_NU: {
       if (!h->g.mut) return VMR_OK;
       Prof p(h, VMR_KERNEL_FINALIZE);
-      hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->slotR, h->elbo_dev, 1, 0, h->g);
-      h->slotR_dirty = false;
+      if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
+      hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, 1, 0, h->g);
       HIPCHK(h, hipGetLastError());
       return VMR_OK;
     }
@@ -1816,8 +1779,8 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   const double SX = V, SR = V / 8.0, Srho = 8.0 * g.L * (double)g.N * g.N * g.K;
   switch (kernel_class) {
     case VMR_KERNEL_GAMMA_MASK: *bytes = SR + Srho; break;
-    case VMR_KERNEL_GAMMA_COUNTS: *bytes = SX + Srho; break;
-    case VMR_KERNEL_PHI: *bytes = SX + Srho; break;
+    case VMR_KERNEL_GAMMA_COUNTS: *bytes = SX + Srho; break;   // statistics pass (once per realisation)
+    case VMR_KERNEL_PHI: *bytes = 0.0; break;                  // no pass of its own: phi_shp comes from H
     case VMR_KERNEL_RHO: *bytes = SX + SR + 2.0 * Srho; break;
     case VMR_KERNEL_ELBO: *bytes = SX + SR + 2.0 * Srho; break;
     case VMR_KERNEL_RHO_ELBO: *bytes = SX + SR + 2.0 * Srho; break;
