@@ -870,7 +870,7 @@ struct SumQ {   // ELBO walk: the mirror tie's masked count
 };
 
 template <int K, bool MUT, bool UPDATE, bool ELBO, int PF>
-__global__ __launch_bounds__(TPB, VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, Geo g) {   // ELBO variants: 2 resident (LDS), so 256 VGPRs
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* xt = smem;
   size_t off = (size_t)g.nt * g.stride;
