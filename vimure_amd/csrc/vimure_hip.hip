@@ -1068,7 +1068,8 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 // ------------------------------------------------------------------------------------------
 // gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
 // then phi_rte from the same A with the new E[theta] (model.py:742-749); mutuality off: phi_shp too.
-__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA, Geo g) {
+__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA, double* lutg,
+                                                   int do_phi, Geo g) {
   __shared__ double red[8];
   __shared__ double ela_old[KMAX], gla_old[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
@@ -1124,6 +1125,39 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
       }
     }
   }
+  // (fused sweep) phi right away: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887),
+  // phi_rte as just computed; then the nibble LUT of the new E[theta] for the rho pass
+  __syncthreads();
+  if (do_phi && g.mut) {
+    const double gnu2 = par[o.sc + SC_G_NU];
+    double ps[KMAX];
+    for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
+    for (int m = threadIdx.x; m < g.M; m += TPB) {
+      const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // new (written above by this workgroup)
+      for (int y = 0; y < g.Y; ++y)
+        for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu2 * (double)y) * Hl[((size_t)y * g.Mp + m) * K + k];
+    }
+    for (int k = 0; k < K; ++k) {
+      double v = block_sum(ps[k], red);
+      if (threadIdx.x == 0) {
+        const int q = l * K + k;
+        double shp = par[o.a_la + q] + v, rte = par[o.p_rte_pend + q];
+        par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
+        double lg = digamma_pos(shp) - log(rte);
+        par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+      }
+    }
+  }
+  const double* Eth = par + o.E_th + (size_t)l * g.Mp;
+  for (int q = threadIdx.x; q < g.W * 256; q += TPB) {
+    int n = q >> 4, e = q & 15;
+    double v = 0.0;
+    for (int u = 0; u < 4; ++u) {
+      int m = n * 4 + u;
+      if (((e >> u) & 1) && m < g.Mp) v += Eth[m];
+    }
+    lutg[(size_t)l * g.W * 256 + q] = v;
+  }
 }
 
 // phi commit, mutuality on: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887; the cache
@@ -1161,41 +1195,63 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
   return lgamma(qa) - pa * log(qb) + (pa - qa) * digamma_pos(qa) + qa * (1.0 - pb / qb);
 }
 
-// nu from H of the new rho (model.py:694-696, 822-825: sum x w2_k rho_k) and/or ELBO assembly (model.py:997-1013)
+// nu from H of the new rho (model.py:694-696, 822-825: sum x w2_k rho_k) and/or ELBO assembly (model.py:997-1013).
+// One workgroup per layer adds its share to fin[0..1] with device-scope atomics; the workgroup that draws the
+// last ticket (fin[2]) finishes the scalars and clears the scratch.
 __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, const double* __restrict__ Hg, double* slotR, double* elbo_out,
-                                                 int do_nu, int do_elbo, Geo g) {
+                                                 double* fin, int do_nu, int do_elbo, Geo g) {
   __shared__ double red[8];
+  __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const int l = blockIdx.x;
+  double a0 = 0.0, gt = 0.0;
   if (g.mut) {
     const double gnu = sc[SC_G_NU];
-    for (int q = threadIdx.x; q < g.L * g.M; q += TPB) {
-      const int l = q / g.M, m = q - l * g.M;
+    const double* Hl = Hg + (size_t)l * g.Y * g.Mp * g.K;
+    for (int m = threadIdx.x; m < g.M; m += TPB) {
       const double gth = par[o.G_th + (size_t)l * g.Mp + m];
-      const double* Hl = Hg + (size_t)l * g.Y * g.Mp * g.K;
-      for (int y = 1; y < g.Y; ++y)
-        for (int k = 0; k < g.K; ++k) {
-          const double z1 = gth * par[o.G_la + l * g.K + k], z2 = gnu * (double)y;
+      for (int k = 0; k < g.K; ++k) {
+        const double z1 = gth * par[o.G_la + l * g.K + k];
+        for (int y = 1; y < g.Y; ++y) {
+          const double z2 = gnu * (double)y;
           a0 += (z2 / (z1 + z2)) * Hl[((size_t)y * g.Mp + m) * g.K + k];
         }
+      }
     }
   }
+  if (do_elbo) {
+    for (int m = threadIdx.x; m < g.M; m += TPB) {
+      const size_t q = (size_t)l * g.Mp + m;
+      gt += gamma_elbo_term(par[o.a_th + q], par[o.b_th + q], par[o.g_shp + q], par[o.g_rte + q]);
+    }
+    for (int k = threadIdx.x; k < g.K; k += TPB) {
+      const int q = l * g.K + k;
+      gt += gamma_elbo_term(par[o.a_la + q], par[o.b_la + q], par[o.p_shp + q], par[o.p_rte + q]);
+    }
+  }
+  a0 = block_sum(a0, red);
+  gt = block_sum(gt, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&fin[0], a0);
+    atomicAdd(&fin[1], gt);
+    __threadfence();
+    const double t = atomicAdd(&fin[2], 1.0);
+    last = (t == (double)(gridDim.x - 1));
+  }
+  __syncthreads();
+  if (!last) return;
+  double a1 = 0, a2 = 0, a3 = 0;
   if (threadIdx.x < NSLOT) {
     double* ps = slotR + (size_t)threadIdx.x * 4;
     a1 = ps[1]; a2 = ps[2]; a3 = ps[3];
     ps[0] = ps[1] = ps[2] = ps[3] = 0.0;   // consume
   }
-  a0 = block_sum(a0, red); a1 = block_sum(a1, red); a2 = block_sum(a2, red); a3 = block_sum(a3, red);
-  double gt = 0.0;
-  if (do_elbo) {
-    for (int q = threadIdx.x; q < g.L * g.Mp; q += TPB)
-      if (q % g.Mp < g.M) gt += gamma_elbo_term(par[o.a_th + q], par[o.b_th + q], par[o.g_shp + q], par[o.g_rte + q]);
-    for (int q = threadIdx.x; q < g.L * g.K; q += TPB)
-      gt += gamma_elbo_term(par[o.a_la + q], par[o.b_la + q], par[o.p_shp + q], par[o.p_rte + q]);
-    gt = block_sum(gt, red);
-  }
+  a1 = block_sum(a1, red); a2 = block_sum(a2, red); a3 = block_sum(a3, red);
   if (threadIdx.x == 0) {
+    a0 = atomicAdd(&fin[0], 0.0);   // device-scope reads of the other workgroups' sums
+    gt = atomicAdd(&fin[1], 0.0);
+    fin[0] = 0.0; fin[1] = 0.0; fin[2] = 0.0;
     if (do_nu && g.mut) {
       sc[SC_G_NU_STALE] = sc[SC_G_NU];           // what the last cache refresh held (model.py:684)
       sc[SC_NU_SHP] = sc[SC_A_ETA] + a0;
@@ -1327,7 +1383,7 @@ static int launch_hist(vmr_ctx* h) {
   return VMR_OK;
 }
 
-static int launch_gamma(vmr_ctx* h) {
+static int launch_gamma(vmr_ctx* h, bool with_phi) {
   const Geo& g = h->g;
   // fork: the mask sums A = sum_ij R rho (memory-bound) run beside the statistics pass when one is needed
   hipStream_t ms = (h->serial || h->h_valid) ? h->stream : h->stream2;
@@ -1356,8 +1412,7 @@ static int launch_gamma(vmr_ctx* h) {
   }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, g);
-    hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, h->lutg, with_phi ? 1 : 0, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -1398,7 +1453,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (mode != 2) h->h_valid = true;
   if (mode != 0 || commit_nu) {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev,
+    hipLaunchKernelGGL(k_fin_rho, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4,
                        (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0, g);
   }
   HIPCHK(h, hipGetLastError());
@@ -1510,7 +1565,8 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     CCHK(hipMalloc(&h->Hg, (size_t)L * g.Y * g.Mp * K * 8));
     CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * g.Y * g.Mp * K * 8, h->stream));
   }
-  CCHK(hipMalloc(&h->elbo_dev, 8 * 8));
+  CCHK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
+  CCHK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
   CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
   CCHK(hipStreamSynchronize(h->stream));
 #undef CCHK
@@ -1613,8 +1669,7 @@ static int sweep(vmr_ctx* h, int mode) {
   // (hipGraph replay of the sweep was tried: 58 vs 63 us per sweep on a 100-node network -- the small-fit
   //  regime is bound by the kernels' own fixed costs, not by launch calls; kept eager.)
   int rc;
-  if ((rc = launch_gamma(h))) return rc;
-  if ((rc = launch_phi(h))) return rc;
+  if ((rc = launch_gamma(h, true))) return rc;   // gamma and phi are finished by one kernel
   return launch_rho(h, mode, true);
 }
 
@@ -1649,12 +1704,11 @@ int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sweep_local");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
-  if ((rc = launch_gamma(h))) return rc;
-  if ((rc = launch_phi(h))) return rc;
+  if ((rc = launch_gamma(h, true))) return rc;
   if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;   // rho updated, nu NOT committed
   if (!want_elbo) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, 0, 0, h->g);
+    hipLaunchKernelGGL(k_fin_rho, dim3(h->g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4, 0, 0, h->g);
     HIPCHK(h, hipGetLastError());
   }
   double v[4];
@@ -1678,7 +1732,7 @@ int vmr_sub_step(vmr_handle h, int which) {
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sub_step");
   HIPCHK(h, hipSetDevice(h->device));
   switch (which) {
-    case VMR_STEP_GAMMA: return launch_gamma(h);
+    case VMR_STEP_GAMMA: return launch_gamma(h, false);
     case VMR_STEP_PHI: return launch_phi(h);
     // the rho pass also rebuilds the statistics H the nu update reads; nu is committed by the NU sub-step
     case VMR_STEP_RHO: return launch_rho(h, 0, false);
@@ -1686,7 +1740,7 @@ int vmr_sub_step(vmr_handle h, int which) {
       if (!h->g.mut) return VMR_OK;
       Prof p(h, VMR_KERNEL_FINALIZE);
       if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
-      hipLaunchKernelGGL(k_fin_rho, dim3(1), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, 1, 0, h->g);
+      hipLaunchKernelGGL(k_fin_rho, dim3(h->g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4, 1, 0, h->g);
       HIPCHK(h, hipGetLastError());
       return VMR_OK;
     }
