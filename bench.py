@@ -168,6 +168,15 @@ def main():
                             if v["ms"] > 0 and v["bytes_per_launch"] > 0 else None} for k, v in prof.items()},
             "elbo": elbos, "gen_seconds": t_gen,
         }
+        # whole-sweep view: SURVEY 8(d)'s canonical bytes per iteration (three passes over X,R + ELBO share) against
+        # the wall time of a sweep -- the engine needs ONE pass over X per sweep (sufficient statistics)
+        V = float(L) * N * N * M
+        srho = 8.0 * L * N * N * K
+        b_iter = 3.0 * (V + V / 8.0) + 4.0 * srho
+        b_elbo = (V + V / 8.0) + 2.0 * srho
+        out["sweep"] = {"canonical_bytes_per_iter": b_iter + b_elbo / 10.0,
+                        "canonical_equiv_GBps": (b_iter + b_elbo / 10.0) / (dt / args.steps) / 1e9,
+                        "iter_per_s_at_8TBps_canonical": HBM_PEAK_GBS * 1e9 / (b_iter + b_elbo / 10.0)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds, eng)
         print(json.dumps(out), flush=True)
