@@ -57,6 +57,9 @@ struct Geo {
   int Gl;       // workgroups per layer for tile-pair kernels
   int Gm;       // workgroups per layer for the mask kernel
   int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
+  int hc;       // how many of them (0..HC_MAX) are accumulated in LDS; the rest goes to global atomics
+  int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
+                // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
   int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
   int dbg;      // timing experiments only (env VMR_DEBUG): 1 = skip per-report math, 2 = skip the scan
@@ -717,7 +720,8 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 // ([L][Y][Mp][K] doubles, Y = max count + 1); mirror counts 0..HC-1 are accumulated in LDS, the rest with global
 // f64 atomics.  k_hist builds H from the current rho (start of a fit, sub-step tests).
 // ------------------------------------------------------------------------------------------
-#define HC 3   // mirror-count levels cached in LDS (93 % of the reports at BASELINE config 3)
+#define NH 8       // copies of H in global memory (workgroup gb adds into copy gb % NH): spreads the atomics
+#define HC_MAX 3   // mirror-count levels cached in LDS when they fit (93 % of the reports at BASELINE config 3); Geo.hc
 
 struct HistArgs {
   const uint8_t* X; const double* rho; double* Hg;
@@ -762,8 +766,8 @@ struct TileIter {
 // one report into H: LDS cache for small mirror counts, global atomics beyond
 template <int K>
 __device__ __forceinline__ void hist_add(double* Hc, double* Hl /*layer's [Y][Mp][K]*/, int Mp, int m, unsigned y,
-                                         double dx, const double* r) {
-  if (y < HC) {
+                                         double dx, const double* r, unsigned hc) {
+  if (y < hc) {
     double* d = Hc + ((size_t)y * Mp + m) * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) atomicAdd(&d[k], dx * r[k]);
@@ -786,12 +790,12 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_hist(HistArgs a, Geo g) 
   unsigned char* xt = smem;
   double* rt = reinterpret_cast<double*>(smem + (size_t)g.nt * g.stride);   // rho of the pair's ties [nt][K]
   double* Hc = rt + (size_t)g.nt * K;                                        // [HC][Mp][K]
-  const int nHc = (MUT ? HC : 1) * g.Mp * K;
+  const int nHc = g.hc * g.Mp * K;
   unsigned short* wq = reinterpret_cast<unsigned short*>(Hc + nHc) + (threadIdx.x >> 6) * (64 * QCAP);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const long long p0 = (long long)gb * g.P / a.Gl, p1 = (long long)(gb + 1) * g.P / a.Gl;
   for (int q = threadIdx.x; q < nHc; q += TPB) Hc[q] = 0.0;
-  double* Hl = a.Hg + (size_t)l * g.Y * g.Mp * K;
+  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
   TileIter it;
   it.init(g, p0);
   const int tau = threadIdx.x >> g.lS, s = threadIdx.x & (g.S - 1);
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(TPB, VMR_LB_COUNTS) void k_hist(HistArgs a, Geo g) 
     sc.walk<NoAcc>(xt, g, tau, s, act, wq,
       [&](int te, int m, unsigned x, NoAcc&) {
         const unsigned y = MUT ? (unsigned)xt[cur.mirror(te) * g.stride + m] : 0u;
-        hist_add<K>(Hc, Hl, g.Mp, m, y, (double)x, rt + te * K);
+        hist_add<K>(Hc, Hl, g.Mp, m, y, (double)x, rt + te * K, (unsigned)g.hc);
       },
       [&](int, const NoAcc&) {});
     __syncthreads();
@@ -881,7 +885,8 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
   double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
   double* ut = reinterpret_cast<double*>(smem + off); off += (size_t)g.nt * K * 8;    // U per tie; exp(rho) in the ELBO walk
   double* rt = reinterpret_cast<double*>(smem + off); off += (size_t)g.nt * K * 8;    // (new) rho per tie
-  const int nHc = UPDATE ? (MUT ? HC : 1) * g.Mp * K : 0;
+  const bool do_hist = UPDATE && !g.two_pass;
+  const int nHc = do_hist ? g.hc * g.Mp * K : 0;
   double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;
   double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
   unsigned* qs = reinterpret_cast<unsigned*>(smem + off); off += ELBO ? (size_t)g.nt * 4 : 0;
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
   const double eps = g.eps;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
-  double* Hl = a.Hg + (size_t)l * g.Y * g.Mp * K;
+  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
 
   TileIter it;
   it.init(g, p0);
@@ -1014,12 +1019,12 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
     }
     if (ELBO) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // Q crosses waves, the rest is wave-local
     // walk 2: H of the new rho; ELBO log terms and mirror sums
-    sc.walk<SumQ>(xt, g, tau, s, act, wq,
+    if (do_hist || ELBO) sc.walk<SumQ>(xt, g, tau, s, act, wq,
       [&](int te, int m, unsigned x, SumQ& acc) {
         const double dx = (double)x;
         const int mt = cur.mirror(te);
         const unsigned y = MUT ? (unsigned)xt[mt * g.stride + m] : 0u;
-        if (UPDATE) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + te * K);
+        if (do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + te * K, (unsigned)g.hc);
         if (ELBO) {
           const bool in_r = (rw[te * g.W + (m >> 6)] >> (m & 63)) & 1ull;
           double inner = 0.0;
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
     }
     __syncthreads();
   }
-  if (UPDATE) hist_flush(Hc, Hl, nHc);
+  if (do_hist) hist_flush(Hc, Hl, nHc);
   if (ELBO) {
     double v1 = block_sum(e_lin, red);
     double v2 = block_sum(e_log, red);
@@ -1064,6 +1069,14 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 }
 
 // ------------------------------------------------------------------------------------------
+// H summed over its NH copies
+__device__ __forceinline__ double h_at(const double* Hl0, size_t copy_stride, size_t idx) {
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < NH; ++c) v += Hl0[c * copy_stride + idx];
+  return v;
+}
+
 // finalize kernels (one workgroup per layer / one workgroup)
 // ------------------------------------------------------------------------------------------
 // gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
@@ -1080,7 +1093,8 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
   }
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
-  const double* Hl = Hg + (size_t)l * g.Y * g.Mp * K;
+  const size_t hcs = (size_t)g.Y * g.Mp * K;
+  const double* Hl = Hg + (size_t)l * NH * hcs;
   double pr[KMAX], p0[KMAX];
   for (int k = 0; k < KMAX; ++k) { pr[k] = 0.0; p0[k] = 0.0; }
   for (int m = threadIdx.x; m < g.M; m += TPB) {
@@ -1089,7 +1103,7 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
     double s1 = 0.0;
     for (int y = 0; y < g.Y; ++y)
       for (int k = 0; k < K; ++k) {
-        const double h = Hl[((size_t)y * g.Mp + m) * K + k];
+        const double h = h_at(Hl, hcs, ((size_t)y * g.Mp + m) * K + k);
         s1 += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * h;
         if (y == 0) p0[k] += h;
       }
@@ -1135,7 +1149,7 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
     for (int m = threadIdx.x; m < g.M; m += TPB) {
       const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // new (written above by this workgroup)
       for (int y = 0; y < g.Y; ++y)
-        for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu2 * (double)y) * Hl[((size_t)y * g.Mp + m) * K + k];
+        for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu2 * (double)y) * h_at(Hl, hcs, ((size_t)y * g.Mp + m) * K + k);
     }
     for (int k = 0; k < K; ++k) {
       double v = block_sum(ps[k], red);
@@ -1170,13 +1184,14 @@ __global__ __launch_bounds__(TPB) void k_fin_phi(double* par, const double* __re
   if (threadIdx.x < K) gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
-  const double* Hl = Hg + (size_t)l * g.Y * g.Mp * K;
+  const size_t hcs = (size_t)g.Y * g.Mp * K;
+  const double* Hl = Hg + (size_t)l * NH * hcs;
   double ps[KMAX];
   for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
   for (int m = threadIdx.x; m < g.M; m += TPB) {
     const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // new
     for (int y = 0; y < g.Y; ++y)
-      for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * Hl[((size_t)y * g.Mp + m) * K + k];
+      for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * h_at(Hl, hcs, ((size_t)y * g.Mp + m) * K + k);
   }
   for (int k = 0; k < K; ++k) {
     double v = block_sum(ps[k], red);
@@ -1208,14 +1223,15 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, const double* __re
   double a0 = 0.0, gt = 0.0;
   if (g.mut) {
     const double gnu = sc[SC_G_NU];
-    const double* Hl = Hg + (size_t)l * g.Y * g.Mp * g.K;
+    const size_t hcs = (size_t)g.Y * g.Mp * g.K;
+    const double* Hl = Hg + (size_t)l * NH * hcs;
     for (int m = threadIdx.x; m < g.M; m += TPB) {
       const double gth = par[o.G_th + (size_t)l * g.Mp + m];
       for (int k = 0; k < g.K; ++k) {
         const double z1 = gth * par[o.G_la + l * g.K + k];
         for (int y = 1; y < g.Y; ++y) {
           const double z2 = gnu * (double)y;
-          a0 += (z2 / (z1 + z2)) * Hl[((size_t)y * g.Mp + m) * g.K + k];
+          a0 += (z2 / (z1 + z2)) * h_at(Hl, hcs, ((size_t)y * g.Mp + m) * g.K + k);
         }
       }
     }
@@ -1292,14 +1308,14 @@ static int fail(vmr_handle h, int code, const char* msg) {
 
 static size_t shmem_ct(const Geo& g) { return g.mut ? (size_t)g.Mp * g.K * 8 : 0; }
 static size_t shmem_q() { return (size_t)(TPB / 64) * 64 * QCAP * 2; }
-static size_t shmem_hc(const Geo& g) { return (size_t)(g.mut ? HC : 1) * g.Mp * g.K * 8; }
+static size_t shmem_hc(const Geo& g) { return (size_t)g.hc * g.Mp * g.K * 8; }
 static size_t shmem_hist(const Geo& g) {
   return (size_t)g.nt * g.stride + (size_t)g.nt * g.K * 8 + shmem_hc(g) + shmem_q() + 16;
 }
 static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
   size_t n = (size_t)g.nt * g.stride + (size_t)g.nt * g.W * 8 + (size_t)g.W * 8 + (size_t)g.Mp * 8 + 64 + shmem_ct(g) +
              2 * (size_t)g.nt * g.K * 8 + shmem_q();
-  if (update) n += shmem_hc(g);
+  if (update && !g.two_pass) n += shmem_hc(g);
   if (elbo) n += (size_t)g.Mp * 8 + (size_t)g.nt * 4;
   return n + 16;
 }
@@ -1364,7 +1380,7 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
 static int launch_hist(vmr_ctx* h) {
   const Geo& g = h->g;
-  HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * g.Y * g.Mp * g.K * 8, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     HistArgs a{h->X, h->rho, h->Hg, 1};
@@ -1437,7 +1453,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
-  if (mode != 2) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
+  if (mode != 2 && !g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
@@ -1450,7 +1466,10 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     }
 #undef LRHO
   }
-  if (mode != 2) h->h_valid = true;
+  if (mode != 2) {
+    h->h_valid = !g.two_pass;
+    if (g.two_pass && (rc = launch_hist(h))) return rc;   // wide reporter dimension: second pass rebuilds H
+  }
   if (mode != 0 || commit_nu) {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_rho, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4,
@@ -1477,6 +1496,8 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.P = (long long)g.nb * (g.nb + 1) / 2;
   g.Gl = 0;   // per launch, see grid_per_layer()
   g.Y = 1;    // set by vmr_create once the largest count is known
+  g.hc = 0;
+  g.two_pass = 0;
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
@@ -1562,8 +1583,17 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     unsigned xm = 0;
     CCHK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
     g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
-    CCHK(hipMalloc(&h->Hg, (size_t)L * g.Y * g.Mp * K * 8));
-    CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * g.Y * g.Mp * K * 8, h->stream));
+    // LDS levels of H (mirror counts 0..hc-1; higher counts are rare and go to global atomics, which are slow
+    // for scattered 8-byte adds): all of min(Y, HC_MAX) must fit.  Beside the rho pass' tables when that keeps
+    // >= 2 workgroups per CU resident (one pass per sweep); otherwise in k_hist alone (two passes per sweep).
+    g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
+    g.two_pass = 0;
+    if (shmem_rho(g, true, false) > 80000) {
+      g.two_pass = 1;
+      while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
+    }
+    CCHK(hipMalloc(&h->Hg, (size_t)L * NH * g.Y * g.Mp * K * 8));
+    CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
   }
   CCHK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
   CCHK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
