@@ -19,6 +19,9 @@ def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2):
         R = None
     elif mask == "random":
         R = (g.rand(L, N, N, M) < 0.7).astype(np.uint8)
+    elif mask == "mixed":   # rows that are all ones (summed by the rho pass), empty, and partial (mask kernel)
+        kind = g.randint(0, 3, size=(L, N, N, 1))
+        R = np.where(kind == 0, 1, np.where(kind == 1, 0, g.rand(L, N, N, M) < 0.5)).astype(np.uint8)
     X = net.X
     pr = vo.make_priors(L, M, K)
     pb_cov = (np.ones((L, N, N), bool) if R is None else R.any(axis=3)) & (X != 0).any(axis=3)
@@ -68,6 +71,10 @@ def test_m200_random_mask_k3():
 
 def test_m1000_tile_edge4_no_mutuality():
     _run(L=1, N=90, M=1000, K=2, eta=0.0, mutuality=False, mask="random", sweeps=2)   # b = 4, 16 mask words
+
+
+def test_mixed_mask_rows_full_empty_partial():
+    _run(L=2, N=120, M=100, K=2, eta=0.5, mutuality=True, mask="mixed", sweeps=4)
 
 
 def test_m50_small_rows():

@@ -58,6 +58,7 @@ struct Geo {
   int Gm;       // workgroups per layer for the mask kernel
   int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
   int hc;       // how many of them (0..HC_MAX) are accumulated in LDS; the rest goes to global atomics
+  int fuse_full; // W <= 4: rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
   int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
@@ -88,6 +89,10 @@ struct vmr_ctx {
   double *slotA = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
   double* Hg = nullptr;        // sufficient statistics H[L][Y][Mp][K]
   bool h_valid = false;        // H matches the current rho
+  double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
+  bool f_valid = false;        // slotF matches the current rho
+  unsigned long long* npartial = nullptr;   // rows of R that are neither empty nor all ones
+  unsigned long long n_partial = 0;
   unsigned* xmax = nullptr;
   double* elbo_dev = nullptr;  // [0] elbo
   double* lutg = nullptr;      // wide masks (W > 4): the nibble LUT of E[theta] lives in global memory [L][W*256]
@@ -527,8 +532,9 @@ __global__ void k_pack_r(const uint8_t* __restrict__ src, uint64_t* __restrict__
 
 // coverage flag per tie + sum(X)
 __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restrict__ Rb, uint8_t* __restrict__ cov,
-                        unsigned long long* sumx, unsigned* xmax, size_t rows, int Mp, int W) {
-  unsigned long long local = 0;
+                        unsigned long long* sumx, unsigned* xmax, unsigned long long* npartial, size_t rows, int Mp,
+                        int W, int M) {
+  unsigned long long local = 0, lpart = 0;
   unsigned lmax = 0;
   for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
     bool anyx = false, anyr = false;
@@ -544,10 +550,19 @@ __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restric
         }
       }
     }
-    for (int w = 0; w < W; ++w) anyr |= Rb[r * W + w] != 0;
+    bool full = true;
+    for (int w = 0; w < W; ++w) {
+      const uint64_t bits = Rb[r * W + w];
+      const int rem = M - w * 64;
+      const uint64_t fm = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      anyr |= bits != 0;
+      full = full && (bits == fm);
+    }
     cov[r] = (anyx && anyr) ? 1 : 0;
+    if (anyr && !full) ++lpart;
   }
   if (local) atomicAdd(sumx, local);
+  if (lpart) atomicAdd(npartial, lpart);
   if (lmax) atomicMax(xmax, lmax);
 }
 
@@ -615,7 +630,7 @@ __global__ void k_derive_all(double* par, Geo g) {
 // (lane <-> reporter).
 template <int K, int NC>
 __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__ Rb, const double* __restrict__ rho,
-                                                    double* __restrict__ slotA, Geo g) {
+                                                    double* __restrict__ slotA, int skip_full, Geo g) {
   __shared__ double sacc[NC * 64 * K];
   const int l = blockIdx.x / g.Gm, gb = blockIdx.x - l * g.Gm;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
         if (c < nc) { full = full && (w[c] == fm[c]); any = any || (w[c] != 0ull); }
       }
 #pragma unroll
-      for (int k = 0; k < K; ++k) accF[k] += full ? r[k] : 0.0;
+      for (int k = 0; k < K; ++k) accF[k] += (full && !skip_full) ? r[k] : 0.0;   // skip_full: the rho pass summed them
       uint64_t todo = __ballot(any && !full);
       while (todo) {
         int i = __builtin_ctzll(todo);
@@ -849,6 +864,7 @@ struct RhoArgs {
   double* slotR;
   const double* lutg;   // nibble LUT of E[theta], [L][W*256]
   double* Hg;
+  double* slotF;
   int Gl;
 };
 
@@ -916,6 +932,11 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];
   const double eps = g.eps;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
+  double accF[K];   // sum of the new rho over this workgroup's ties whose mask row is all ones
+#pragma unroll
+  for (int k = 0; k < K; ++k) accF[k] = 0.0;
+  const int lastrem = g.M - (g.W - 1) * 64;
+  const uint64_t lastfull = lastrem >= 64 ? ~0ull : ((1ull << lastrem) - 1ull);
   if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
 
@@ -963,16 +984,21 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
     it.next();
     if (p + 1 < p1) { ts.fetch(Xl, g, it.I * g.b, it.J * g.b); ms.fetch(Rl, g, it.I * g.b, it.J * g.b); fetch_tie(); }
     double Tt = 0.0;
+    int rowfull = 1;
     if (act) {
       // T = sum_m R E[theta_m] (model.py:766-792): whole-word shortcut, else nibble look-ups
       const uint64_t* rwt = rw + (size_t)tau * g.W;
       for (int w = s; w < g.W; w += g.S) {
         uint64_t bits = rwt[w];
+        rowfull &= (bits == (w == g.W - 1 ? lastfull : ~0ull)) ? 1 : 0;
         if (bits == ~0ull) { Tt += wsum[w]; continue; }
         for (int n = 0; bits != 0; ++n, bits >>= 4) Tt += lut[((w * 16 + n) << 4) + (unsigned)(bits & 15u)];
       }
     }
     Tt = group_sum(Tt, g.S);
+    if (UPDATE && g.fuse_full) {
+      for (int o2 = g.S >> 1; o2 > 0; o2 >>= 1) rowfull &= __shfl_xor(rowfull, o2, 64);
+    }
     TileScan sc;
     sc.build(xt, g, tau, s, act, wq);
     if (UPDATE) {
@@ -1006,7 +1032,10 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
       }
       if (act && s == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) rl[tg * K + k] = r[k];
+        for (int k = 0; k < K; ++k) {
+          rl[tg * K + k] = r[k];
+          accF[k] += (g.fuse_full && rowfull) ? r[k] : 0.0;
+        }
       }
     }
     if (s == 0 && tau < g.nt) {
@@ -1057,6 +1086,13 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
     __syncthreads();
   }
   if (do_hist) hist_flush(Hc, Hl, nHc);
+  if (UPDATE && g.fuse_full) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double v = block_sum(accF[k], red);
+      if (threadIdx.x == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
+    }
+  }
   if (ELBO) {
     double v1 = block_sum(e_lin, red);
     double v2 = block_sum(e_log, red);
@@ -1081,13 +1117,16 @@ __device__ __forceinline__ double h_at(const double* Hl0, size_t copy_stride, si
 // ------------------------------------------------------------------------------------------
 // gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
 // then phi_rte from the same A with the new E[theta] (model.py:742-749); mutuality off: phi_shp too.
-__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA, double* lutg,
-                                                   int do_phi, Geo g) {
+__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA,
+                                                   const double* __restrict__ slotF, double* lutg, int do_phi, Geo g) {
   __shared__ double red[8];
-  __shared__ double ela_old[KMAX], gla_old[KMAX];
+  __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K, Wp = g.W * 64;
   if (threadIdx.x < K) {
+    double f = 0.0;   // all-ones mask rows, summed by the rho pass (zero when the mask kernel handled them)
+    for (int sl = 0; sl < NSLOT; ++sl) f += slotF[((size_t)l * NSLOT + sl) * K + threadIdx.x];
+    fk[threadIdx.x] = f;
     ela_old[threadIdx.x] = par[o.p_shp + l * K + threadIdx.x] / par[o.p_rte + l * K + threadIdx.x];
     gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
   }
@@ -1114,6 +1153,7 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
         double* pa = &slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];
         ak += *pa; *pa = 0.0;   // consume: the slots are zero again for the next sweep
       }
+      ak += fk[k];
       A[k] = ak;
       rte += ela_old[k] * ak;
     }
@@ -1407,14 +1447,17 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(h, hipStreamWaitEvent(ms, h->ev_fork, 0));
   }
-  {
+  // mask rows that are all ones were already summed by the last rho pass (slotF); the mask kernel then only
+  // handles partial rows, and is not needed at all when R has none
+  const int skip_full = (g.fuse_full && h->f_valid) ? 1 : 0;
+  if (!skip_full || h->n_partial > 0) {
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
     switch (g.W >= 4 ? 4 : g.W) {
-      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
-      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
-      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
-      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, g)); break;
+      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
+      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
+      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
+      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
     }
   }
   if (ms != h->stream) {
@@ -1428,7 +1471,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
   }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, h->lutg, with_phi ? 1 : 0, g);
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg, with_phi ? 1 : 0, g);
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -1449,10 +1492,11 @@ static int launch_phi(vmr_ctx* h) {
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   const Geo& g = h->g;
-  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, 1};
+  RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
+  if (mode != 2 && g.fuse_full) HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   if (mode != 2 && !g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
@@ -1467,6 +1511,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
 #undef LRHO
   }
   if (mode != 2) {
+    h->f_valid = g.fuse_full != 0;
     h->h_valid = !g.two_pass;
     if (g.two_pass && (rc = launch_hist(h))) return rc;   // wide reporter dimension: second pass rebuilds H
   }
@@ -1498,6 +1543,7 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.Y = 1;    // set by vmr_create once the largest count is known
   g.hc = 0;
   g.two_pass = 0;
+  g.fuse_full = 0;
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
@@ -1556,6 +1602,8 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
   CCHK(hipMalloc(&h->xmax, 4));
   CCHK(hipMemsetAsync(h->xmax, 0, 4, h->stream));
+  CCHK(hipMalloc(&h->npartial, 8));
+  CCHK(hipMemsetAsync(h->npartial, 0, 8, h->stream));
   {
     uint8_t* tmp = nullptr;
     const uint8_t* src = X;
@@ -1566,7 +1614,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     tmp = nullptr; src = R;
     if (R && !data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
     hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
-    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, h->xmax, rows, g.Mp, g.W);
+    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
     CCHK(hipStreamSynchronize(h->stream));
     if (tmp) CCHK(hipFree(tmp));
   }
@@ -1582,6 +1630,10 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     CCHK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CCHK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
     unsigned xm = 0;
     CCHK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
+    CCHK(hipMemcpy(&h->n_partial, h->npartial, 8, hipMemcpyDeviceToHost));
+    g.fuse_full = (g.W <= 4) ? 1 : 0;
+    CCHK(hipMalloc(&h->slotF, (size_t)L * NSLOT * K * 8));
+    CCHK(hipMemsetAsync(h->slotF, 0, (size_t)L * NSLOT * K * 8, h->stream));
     g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
     // LDS levels of H (mirror counts 0..hc-1; higher counts are rare and go to global atomics, which are slow
     // for scattered 8-byte adds): all of min(Y, HC_MAX) must fit.  Beside the rho pass' tables when that keeps
@@ -1609,7 +1661,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax};
+  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1685,6 +1737,8 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
   h->h_valid = false;
+  h->f_valid = false;
+  HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   return VMR_OK;
 }
 
