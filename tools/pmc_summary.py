@@ -8,12 +8,18 @@ are in KiB; on gfx950 FETCH_SIZE reports exactly half of a wide (16 B/lane) coal
 read side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
 import collections
 import csv
-import glob
+import glob as _glob
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class glob:   # newest match first (a profile directory may hold earlier runs)
+    @staticmethod
+    def glob(pat):
+        return sorted(_glob.glob(pat), key=os.path.getmtime, reverse=True)
 CLASS = [("k_gamma_mask", "gamma_mask"), ("k_gamma_counts", "gamma_counts"), ("k_phi", "phi"),
          ("true, true, true", "rho_elbo"), ("false, true, true", "rho_elbo"), ("k_rho", "rho")]
 
