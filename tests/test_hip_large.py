@@ -77,6 +77,29 @@ def test_mixed_mask_rows_full_empty_partial():
     _run(L=2, N=120, M=100, K=2, eta=0.5, mutuality=True, mask="mixed", sweeps=4)
 
 
+def test_m2000_tile_edge2():
+    _run(L=1, N=40, M=2000, K=2, eta=0.5, mutuality=True, mask="random", sweeps=2)     # b = 2, 32 lanes per tie
+
+
+def test_m7000_tile_edge1_chunk_walk():
+    _run(L=1, N=20, M=7000, K=2, eta=0.0, mutuality=False, mask="ones", sweeps=2)      # b = 1, 64 lanes per tie
+
+
+def test_m4500_mutuality_tables_fill_lds():
+    _run(L=1, N=24, M=4500, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2)     # ~155 KB of LDS tables
+
+
+def test_reporter_tables_beyond_lds_are_refused():
+    from vimure_amd.engine import CaviEngine
+    X = np.zeros((1, 4, 4, 7000), np.uint8)
+    with pytest.raises(ValueError, match="LDS"):
+        CaviEngine(X, None, K=2, mutuality=True)
+
+
+def test_k5_categories():
+    _run(L=1, N=150, M=64, K=5, eta=0.5, mutuality=True, mask="mixed", sweeps=3)
+
+
 def test_m50_small_rows():
     _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones")
 

@@ -6,15 +6,15 @@
 // dense uint8 report tensor X[L,N,N,Mp] and a bit-packed reporter mask R, behind the C-ABI of
 // include/vimure_hip.h.  Design notes, data layout and byte accounting: DESIGN.md.
 //
-// Kernel families
-//   k_gamma_mask   lane <-> reporter m, tie wave-uniform: R-row words arrive by scalar loads and
-//                  become the EXEC mask of K v_add_f64 -- A[l,m,k] = sum_ij R[l,i,j,m] rho[l,i,j,k].
-//   k_hist / k_rho   "tile-pair" sweeps over X: a workgroup stages the (I,J) tile
-//                  of ties and its mirror (J,I) in LDS so that X[l,j,i,m] (the reference's
-//                  data_T_vals) is an LDS byte read; S lanes own one tie row, skip zero 16-B
-//                  chunks and run the per-report arithmetic only on non-zero counts.
-//   k_fin_*        single-workgroup reductions of the per-workgroup partials + the Gamma
-//                  expectations (digamma/log/exp) -- no host round trip inside a sweep.
+// One sweep touches X once:  k_gamma_mask (partial mask rows) -> k_fin_gamma -> k_rho -> k_fin_rho.
+//   k_rho          "tile-pair" sweep over X: a workgroup stages the (I,J) tile of ties and its mirror (J,I) in
+//                  LDS so that X[l,j,i,m] (the reference's data_T_vals) is an LDS byte read; the non-zero counts
+//                  of the pair are compacted into wave-local queues and walked twice: per-tie sums for the rho
+//                  update, then the sufficient statistics H[l,y,m,k] of the new rho (and the ELBO data terms).
+//   k_hist         the same sweep building H from the current rho (start of a realisation).
+//   k_gamma_mask   A[l,m,k] = sum_ij R rho: mask words become the EXEC mask of K v_add_f64 (lane <-> reporter).
+//   k_fin_*        one workgroup per layer: gamma, phi, nu from H and A, the Gamma expectations
+//                  (digamma/log/exp), ELBO assembly -- no host round trip inside a sweep.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -138,6 +138,7 @@ __host__ __device__ static inline ParOff par_off(int L, int Mp, int K) {
       char buf_[512];                                                                \
       snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
       if (h) (h)->err = buf_; else g_create_err = buf_;                              \
+      (void)hipGetLastError(); /* do not leave the error sticky for the next call */ \
       return VMR_EHIP;                                                               \
     }                                                                                \
   } while (0)
@@ -743,15 +744,6 @@ struct HistArgs {
   int Gl;   // workgroups per layer of this launch
 };
 
-template <int K>
-struct SumK {
-  double v[K];
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = 0.0;
-  }
-};
-
 // common per-tile bookkeeping of the tile-pair kernels
 struct TileIter {
   int I, J, nb, b, lb, bb, N;
@@ -971,7 +963,6 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
     int i, j;
     const bool act = it.coords(tau, i, j);
     const size_t tg = act ? ((size_t)i * g.N + j) : 0;
-    const int mtau = it.mirror(tau);
     const TileIter cur = it;
     double lp[K], r[K];
 #pragma unroll
@@ -1123,7 +1114,7 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K, Wp = g.W * 64;
-  if (threadIdx.x < K) {
+  if ((int)threadIdx.x < K) {
     double f = 0.0;   // all-ones mask rows, summed by the rho pass (zero when the mask kernel handled them)
     for (int sl = 0; sl < NSLOT; ++sl) f += slotF[((size_t)l * NSLOT + sl) * K + threadIdx.x];
     fk[threadIdx.x] = f;
@@ -1221,7 +1212,7 @@ __global__ __launch_bounds__(TPB) void k_fin_phi(double* par, const double* __re
   __shared__ double gla_old[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K;
-  if (threadIdx.x < K) gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
+  if ((int)threadIdx.x < K) gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
   const size_t hcs = (size_t)g.Y * g.Mp * K;
@@ -1530,8 +1521,11 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.stride = (g.nchunk % 2 == 1) ? g.Mp : g.Mp + 16;
   g.W = (g.M + 63) / 64;
   const size_t budget = 48 * 1024;
+  // per-reporter LDS tables of the rho pass beside the tile pair (see shmem_rho): they cap the tile edge too
+  const size_t tables = (size_t)g.Mp * 8 * (2 + (g.mut ? g.K : 0)) + (size_t)g.W * 8 + shmem_q() + 256;
+  auto lds = [&](int b_) { return (size_t)2 * b_ * b_ * (g.stride + (size_t)g.W * 8 + 2 * g.K * 8 + 4) + tables; };
   int b = 8;
-  while (b > 1 && (size_t)2 * b * b * g.stride > budget) b >>= 1;
+  while (b > 1 && ((size_t)2 * b * b * g.stride > budget || lds(b) > 160 * 1024)) b >>= 1;
   if ((size_t)2 * b * b * g.stride > budget) { err = "M too large for the LDS tile (M <= ~24500 supported)"; return VMR_EINVAL; }
   g.b = b; g.lb = (b == 8) ? 3 : (b == 4) ? 2 : (b == 2) ? 1 : 0;
   g.nb = (g.N + b - 1) / b;
@@ -1583,7 +1577,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   std::string err;
   if (choose_geo(g, prop.multiProcessorCount, err) != VMR_OK) { delete h; return fail(nullptr, VMR_EINVAL, err.c_str()); }
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
-#define CCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); vmr_destroy(h); return VMR_EHIP; } } while (0)
+#define CCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); vmr_destroy(h); return VMR_EHIP; } } while (0)
   CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   CCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1609,12 +1603,15 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     const uint8_t* src = X;
     if (!data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, X, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
     hipLaunchKernelGGL(k_pack_x, dim3(4096), dim3(256), 0, h->stream, src, h->X, rows, M, g.Mp);
+    CCHK(hipGetLastError());
     CCHK(hipStreamSynchronize(h->stream));
     if (tmp) CCHK(hipFree(tmp));
     tmp = nullptr; src = R;
     if (R && !data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
     hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
+    CCHK(hipGetLastError());
     hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
+    CCHK(hipGetLastError());
     CCHK(hipStreamSynchronize(h->stream));
     if (tmp) CCHK(hipFree(tmp));
   }
@@ -1643,6 +1640,19 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     if (shmem_rho(g, true, false) > 80000) {
       g.two_pass = 1;
       while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
+    }
+    // the rho pass keeps per-reporter tables in LDS (G_theta, the mutuality weights c[m,k], and log G_theta
+    // for the ELBO variant): (K + 2) * 8 bytes per reporter beside the tile pair.  160 KB per workgroup on gfx950.
+    {
+      size_t need = shmem_rho(g, true, true);
+      if (shmem_hist(g) > need) need = shmem_hist(g);
+      if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
+                 "reduce M or K", M, K, g.mut ? " and mutuality" : "", need, 160 * 1024);
+        vmr_destroy(h);
+        return fail(nullptr, VMR_EINVAL, msg);
+      }
     }
     CCHK(hipMalloc(&h->Hg, (size_t)L * NH * g.Y * g.Mp * K * 8));
     CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
@@ -1731,7 +1741,9 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
     src = h->logpr;
   }
   hipLaunchKernelGGL(k_init_rho, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, n, g.eps);
+  HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_derive_all, dim3(8), dim3(256), 0, h->stream, h->par, g);
+  HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
