@@ -138,9 +138,15 @@ int vmr_sync(vmr_handle h);
 int vmr_profile(vmr_handle h, int enable);
 int vmr_profile_read(vmr_handle h, int kernel_class, double* total_ms, int64_t* launches);
 
-/* Algorithmic bytes one launch of a kernel class moves under the canonical dense encoding
- * (X 1 B/elt, R 1 bit/elt, rho/logpr_rho 8 B), see DESIGN.md. */
+/* Algorithmic bytes one launch of a kernel class moves under the handle's data format, see DESIGN.md:
+ * report lists (4 B per non-zero count, 4 B per tie, mask words of partial rows, rho/logpr_rho 8 B) or the
+ * dense encoding (X 1 B/elt, R 1 bit/elt, rho/logpr_rho 8 B). */
 int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes);
+
+/* Data format chosen by vmr_create: *sparse = 1 for report lists (default whenever they are at most half the
+ * dense bytes; env VMR_FORMAT=dense|sparse overrides), 0 for the dense tiles.  *nnz = non-zero counts in X
+ * (0 when the dense format was forced before counting).  Either pointer may be NULL. */
+int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz);
 
 /* Library/version string. */
 const char* vmr_version(void);

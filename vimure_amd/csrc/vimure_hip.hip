@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 #include <utility>
+#include <algorithm>
 
 #include "vimure_hip.h"
 
@@ -58,7 +59,7 @@ struct Geo {
   int Gm;       // workgroups per layer for the mask kernel
   int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
   int hc;       // how many of them (0..HC_MAX) are accumulated in LDS; the rest goes to global atomics
-  int fuse_full; // W <= 4: rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
+  int fuse_full; // rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
   int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
@@ -80,6 +81,15 @@ struct vmr_ctx {
   uint8_t* X = nullptr;        // [L][N*N][Mp]
   uint64_t* Rb = nullptr;      // [L][N*N][W]
   uint8_t* cov = nullptr;      // [L][N*N]
+  uint8_t* rcls = nullptr;     // [L][N*N] class of the mask row: 0 empty, 1 all ones, 2 partial
+  // report lists (sparse format, see k_rho_sp); X is freed once they exist
+  int sparse = 0;
+  unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
+  unsigned* rp = nullptr;      // [L][N*N+1] first entry of a tie, relative to ebase[l]
+  unsigned* Qt = nullptr;      // [L][N*N] sum_m R[t,m] X[mirror(t),m]
+  unsigned long long* ebase = nullptr;   // device [L]
+  unsigned long long nnz = 0;  // non-zero counts in X
+  int all_full = 0;            // every mask row is all ones
   unsigned long long* sumx = nullptr;
   // state
   double *rho = nullptr, *logpr = nullptr;
@@ -533,9 +543,10 @@ __global__ void k_pack_r(const uint8_t* __restrict__ src, uint64_t* __restrict__
 
 // coverage flag per tie + sum(X)
 __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restrict__ Rb, uint8_t* __restrict__ cov,
+                        uint8_t* __restrict__ rcls,
                         unsigned long long* sumx, unsigned* xmax, unsigned long long* npartial, size_t rows, int Mp,
                         int W, int M) {
-  unsigned long long local = 0, lpart = 0;
+  unsigned long long local = 0, lpart = 0, lempty = 0;
   unsigned lmax = 0;
   for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
     bool anyx = false, anyr = false;
@@ -560,10 +571,13 @@ __global__ void k_stats(const uint8_t* __restrict__ X, const uint64_t* __restric
       full = full && (bits == fm);
     }
     cov[r] = (anyx && anyr) ? 1 : 0;
+    rcls[r] = !anyr ? 0 : (full ? 1 : 2);
     if (anyr && !full) ++lpart;
+    if (!anyr) ++lempty;
   }
   if (local) atomicAdd(sumx, local);
   if (lpart) atomicAdd(npartial, lpart);
+  if (lempty) atomicAdd(npartial + 1, lempty);   // [1]: rows with no reporter at all
   if (lmax) atomicMax(xmax, lmax);
 }
 
@@ -631,7 +645,8 @@ __global__ void k_derive_all(double* par, Geo g) {
 // (lane <-> reporter).
 template <int K, int NC>
 __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__ Rb, const double* __restrict__ rho,
-                                                    double* __restrict__ slotA, int skip_full, Geo g) {
+                                                    const uint8_t* __restrict__ rcls, double* __restrict__ slotA,
+                                                    int skip_full, Geo g) {
   __shared__ double sacc[NC * 64 * K];
   const int l = blockIdx.x / g.Gm, gb = blockIdx.x - l * g.Gm;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -641,6 +656,7 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
   const long long t0 = gw * T / nw, t1 = (gw + 1) * T / nw;
   const uint64_t* Rl = Rb + (size_t)l * T * g.W;
   const double* rl = rho + (size_t)l * T * K;
+  const uint8_t* cl = rcls + (size_t)l * T;
   const int Wp = g.W * 64;
   for (int cg = 0; cg < g.W; cg += NC) {
     const int nc = min(NC, g.W - cg);   // == NC except in the last group of a wide mask
@@ -651,14 +667,9 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c][k] = 0.0;
     }
-    uint64_t fm[NC];   // the word of an every-reporter row (last word: only bits m < M)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      int rem = g.M - (cg + c) * 64;
-      fm[c] = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
-    }
     uint64_t wq[NC];
     double rq[K];
+    unsigned cq = 0;   // the row's class: "all ones" must mean the whole row, not just this group's words
     auto fetch = [&](long long tb) {
       long long t = tb + lane;
       bool ok = t < t1;
@@ -667,6 +678,7 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
       for (int c = 0; c < NC; ++c) wq[c] = (ok && c < nc) ? Rl[tc * g.W + cg + c] : 0ull;
 #pragma unroll
       for (int k = 0; k < K; ++k) rq[k] = ok ? rl[tc * K + k] : 0.0;
+      cq = ok ? (unsigned)cl[tc] : 0u;
     };
     if (t0 < t1) fetch(t0);
     for (long long tb = t0; tb < t1; tb += 64) {
@@ -676,11 +688,12 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
       for (int c = 0; c < NC; ++c) w[c] = wq[c];
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = rq[k];
+      const bool full = cq == 1u;
       if (tb + 64 < t1) fetch(tb + 64);   // in flight during this batch
-      bool full = tb + lane < t1, any = false;
+      bool any = false;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (c < nc) { full = full && (w[c] == fm[c]); any = any || (w[c] != 0ull); }
+        if (c < nc) any = any || (w[c] != 0ull);
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) accF[k] += (full && !skip_full) ? r[k] : 0.0;   // skip_full: the rho pass summed them
@@ -1095,6 +1108,403 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
   }
 }
 
+// ==========================================================================================
+// Report lists (the default data format when X is sparse, which it is: 1.5-5 % of the counts are non-zero)
+//
+// X is a tensor of COUNTS of which a few per cent are non-zero; every update touches only those, and the only
+// thing the mutuality terms need besides a report is the mirrored count X[l,j,i,m].  vmr_create therefore turns
+// the dense tensor into one 4-byte entry per non-zero count, tie after tie:
+//     bits 0..12  reporter m          bit 13      R[l,i,j,m]
+//     bits 16..23 count x             bits 24..31 mirror count y = X[l,j,i,m]  (0 when mutuality is off)
+// with rp[l][t] (u32, N*N+1 per layer) = first entry of tie t, relative to the layer's base, rcls[l][t] = the
+// class of the tie's mask row (0 empty, 1 all ones, 2 partial) and Qt[l][t] = sum_m R[t,m] X[mirror(t),m] (the
+// ELBO's mirror sum, a constant of the data).  A sweep then reads 4 B per report + 4 B per tie + rho/log-prior
+// instead of the 1 B per (tie, reporter) of the dense layout, and no tile pair has to be staged: 4.5 GB -> 1.2 GB
+// per sweep at BASELINE config 3.  The dense tensor is freed once the lists exist.
+// ==========================================================================================
+#define SP_ECAP 4096   // entries of a batch whose owners are resolved through LDS
+#define ENT_M(e) ((int)((e) & 0x1fffu))
+#define ENT_INR(e) (((e) >> 13) & 1u)
+#define ENT_X(e) (((e) >> 16) & 0xffu)
+#define ENT_Y(e) ((e) >> 24)
+
+__device__ __forceinline__ unsigned nz_bytes(uint4 v) {
+  const unsigned M = 0x7f7f7f7fu;
+  unsigned t0 = (((v.x & M) + M) | v.x) & ~M, t1 = (((v.y & M) + M) | v.y) & ~M;
+  unsigned t2 = (((v.z & M) + M) | v.z) & ~M, t3 = (((v.w & M) + M) | v.w) & ~M;
+  return __popc(t0) + __popc(t1) + __popc(t2) + __popc(t3);
+}
+
+// non-zero counts per tie of one layer (16 lanes per row); the layer total goes to *nnz
+__global__ __launch_bounds__(256) void k_sp_count(const uint8_t* __restrict__ Xl, unsigned* __restrict__ rpl,
+                                                  unsigned long long* nnz, size_t T, int Mp) {
+  __shared__ double red[8];
+  const int gl = threadIdx.x & 15, nchunk = Mp / 16;
+  unsigned long long mine = 0;
+  const size_t Tr = (T + 15) / 16 * 16;
+  for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
+    unsigned c = 0;
+    if (t < T) {
+      const uint8_t* row = Xl + t * Mp;
+      for (int ch = gl; ch < nchunk; ch += 16) c += nz_bytes(*reinterpret_cast<const uint4*>(row + ch * 16));
+    }
+    c = group_sum_u(c, 16);
+    if (gl == 0 && t < T) { rpl[t] = c; mine += c; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) rpl[T] = 0u;
+  // block total (exact in double: < 2^53)
+  double v = block_sum((double)mine, red);
+  if (threadIdx.x == 0 && v > 0.0) atomicAdd(nnz, (unsigned long long)v);
+}
+
+// in-place exclusive scan of n u32 items in three launches (2048 items per workgroup)
+__global__ __launch_bounds__(256) void k_scan_local(unsigned* a, unsigned* bsum, size_t n) {
+  __shared__ unsigned sh[256];
+  const size_t base = (size_t)blockIdx.x * 2048 + (size_t)threadIdx.x * 8;
+  unsigned v[8], s = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { unsigned t = (base + u < n) ? a[base + u] : 0u; v[u] = s; s += t; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o2 = 1; o2 < 256; o2 <<= 1) {
+    unsigned t = (threadIdx.x >= (unsigned)o2) ? sh[threadIdx.x - o2] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const unsigned excl = sh[threadIdx.x] - s;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) if (base + u < n) a[base + u] = v[u] + excl;
+  if (threadIdx.x == 255) bsum[blockIdx.x] = sh[255];
+}
+__global__ __launch_bounds__(256) void k_scan_bsum(unsigned* bsum, int nb) {
+  __shared__ unsigned sh[256];
+  unsigned carry = 0;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    const unsigned s = (i < nb) ? bsum[i] : 0u;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o2 = 1; o2 < 256; o2 <<= 1) {
+      unsigned t = (threadIdx.x >= (unsigned)o2) ? sh[threadIdx.x - o2] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) bsum[i] = carry + sh[threadIdx.x] - s;
+    carry += sh[255];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_add(unsigned* a, const unsigned* __restrict__ bsum, size_t n) {
+  const size_t base = (size_t)blockIdx.x * 2048 + (size_t)threadIdx.x * 8;
+  const unsigned add = bsum[blockIdx.x];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) if (base + u < n) a[base + u] += add;
+}
+
+// write the entries of one layer (16 lanes per tie, in reporter order) and the mirror sums Qt
+template <bool MUT>
+__global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
+                                                 const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
+                                                 unsigned* __restrict__ Qtl, Geo g) {
+  const int gl = threadIdx.x & 15;
+  const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
+  for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
+    const bool ok = t < T;
+    const size_t tc = ok ? t : 0;
+    const size_t i = tc / g.N, j = tc - i * g.N, tm = j * g.N + i;
+    const uint8_t* row = Xl + tc * g.Mp;
+    const uint8_t* mrow = Xl + tm * g.Mp;
+    const uint64_t* rr = Rl + tc * g.W;
+    const uint64_t* rmr = Rl + tm * g.W;
+    size_t pos = rpl[tc];
+    unsigned q = 0;
+    for (int c0 = 0; c0 < g.nchunk; c0 += 16) {   // uniform over the 16 lanes
+      const int ch = c0 + gl;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok && ch < g.nchunk) v = *reinterpret_cast<const uint4*>(row + ch * 16);
+      const unsigned n = nz_bytes(v);
+      unsigned incl = n;
+#pragma unroll
+      for (int o2 = 1; o2 < 16; o2 <<= 1) {
+        unsigned up = __shfl_up(incl, o2, 16);
+        if (gl >= o2) incl += up;
+      }
+      const unsigned tot = __shfl(incl, 15, 16);
+      size_t w = pos + incl - n;
+      const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        unsigned dw = d[u];
+        while (dw) {
+          const int sh = __builtin_ctz(dw) & ~7;
+          const unsigned x = (dw >> sh) & 0xffu;
+          dw &= ~(0xffu << sh);
+          const int m = ch * 16 + u * 4 + (sh >> 3);
+          const unsigned inr = (unsigned)((rr[m >> 6] >> (m & 63)) & 1ull);
+          unsigned y = 0;
+          if (MUT) {
+            y = mrow[m];
+            if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
+          }
+          El[w++] = (unsigned)m | (inr << 13) | (x << 16) | (y << 24);
+        }
+      }
+      pos += tot;
+    }
+    q = group_sum_u(q, 16);
+    if (ok && gl == 0) Qtl[tm] = q;   // every tie is the mirror of exactly one tie
+  }
+}
+
+struct SpArgs {
+  const unsigned* E; const unsigned* rp; const unsigned long long* ebase; const uint64_t* Rb; const uint8_t* rcls;
+  double* rho; const double* logpr; const double* par; double* slotR; const double* lutg; double* Hg; double* slotF;
+  const unsigned* Qt;
+  int Gl, all_full, do_hist;
+};
+
+// rho update (UPDATE), ELBO data terms (ELBO) and the statistics H (a.do_hist) from the report lists.
+// A workgroup takes 256 consecutive ties per step, one per thread for the per-tie work (log prior, mask sum T,
+// exp / normalise, write-back); their entries are one contiguous run of the list and are walked entry-parallel
+// (coalesced 4-byte loads, thread <-> entry); owner[] maps an entry to its tie (filled by the tie's thread; long
+// runs by the whole wave).  Walk 1 gathers U_k per tie with LDS atomics, walk 2 (after the per-tie update) adds
+// x * rho_new into H and collects the ELBO's log terms.
+template <int K, bool MUT, bool UPDATE, bool ELBO>
+__global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  size_t off = 0;
+  double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
+  double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
+  double* ut = reinterpret_cast<double*>(smem + off); off += (size_t)TPB * K * 8;   // U per tie; exp(rho) in the ELBO walk
+  double* rt = reinterpret_cast<double*>(smem + off); off += (size_t)TPB * K * 8;   // (new) rho per tie
+  double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
+  double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
+  const int nHc = a.do_hist ? g.hc * g.Mp * K : 0;
+  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;
+  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
+  unsigned* rps = reinterpret_cast<unsigned*>(smem + off); off += (size_t)(TPB + 2) * 4;
+  unsigned char* owner = smem + off;
+  const ParOff o = par_off(g.L, g.Mp, g.K);
+  const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
+  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const size_t T = (size_t)g.N * g.N;
+  const long long NB = (long long)((T + TPB - 1) / TPB);
+  const long long b0 = (long long)gb * NB / a.Gl, b1 = (long long)(gb + 1) * NB / a.Gl;
+  for (int m = tid; m < g.Mp; m += TPB) {
+    lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
+    if (ELBO) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
+  }
+  for (int q = tid; q < nHc; q += TPB) Hc[q] = 0.0;
+  const double* lut = a.lutg + (size_t)l * g.W * 256;
+  for (int w = tid; w < g.W; w += TPB) {
+    double v = 0.0;
+    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
+    wsum[w] = v;
+  }
+  double Ela[K], lla[K], Gla[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    Ela[k] = a.par[o.E_la + l * K + k]; lla[k] = a.par[o.l_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k];
+  }
+  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  const double eps = g.eps;
+  double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
+  double accF[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) accF[k] = 0.0;
+  if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
+  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
+  const unsigned* rpl = a.rp + (size_t)l * (T + 1);
+  const unsigned* El = a.E + a.ebase[l];
+  const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
+  const uint8_t* cl = a.rcls + (size_t)l * T;
+  const unsigned* Ql = a.Qt + (size_t)l * T;
+  double* rl = a.rho + (size_t)l * T * K;
+  const double* lpl = a.logpr + (size_t)l * T * K;
+
+  unsigned r0n = 0, r1n = 0, clsn = 0, qn = 0;
+  double lpn[K], rn[K];
+  auto fetch_tie = [&](long long blk) {
+    const size_t t = (size_t)blk * TPB + tid;
+    const bool ok = t < T;
+    r0n = rpl[ok ? t : T];
+    r1n = rpl[ok ? t + 1 : T];
+    clsn = ok ? (a.all_full ? 1u : (unsigned)cl[t]) : 0u;
+    if (ELBO && MUT) qn = ok ? Ql[t] : 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      lpn[k] = ((UPDATE || ELBO) && ok) ? lpl[t * K + k] : 0.0;
+      rn[k] = (!UPDATE && ok) ? rl[t * K + k] : 0.0;
+    }
+  };
+  if (b0 < b1) fetch_tie(b0);
+  __syncthreads();
+  double Tfull = 0.0;
+  for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
+
+  for (long long blk = b0; blk < b1; ++blk) {
+    const size_t t = (size_t)blk * TPB + tid;
+    const bool act = t < T;
+    const unsigned r0 = r0n, r1 = r1n, cls = clsn, qt = qn;
+    double lp[K], r[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
+    rps[tid] = r0;
+    if (tid == TPB - 1) rps[TPB] = r1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (UPDATE) ut[tid * K + k] = 0.0;
+      else { rt[tid * K + k] = r[k]; if (ELBO) ut[tid * K + k] = exp(r[k]); }
+    }
+    if (blk + 1 < b1) fetch_tie(blk + 1);   // in flight while this step is processed
+    double Tt = 0.0;
+    bool rowfull = false;
+    if (UPDATE || ELBO) {   // T = sum_m R E[theta_m] (model.py:766-792)
+      if (cls == 1u) { Tt = Tfull; rowfull = true; }
+      else if (cls == 2u) {
+        const uint64_t* rwt = Rl + t * g.W;
+        for (int w = 0; w < g.W; ++w) {
+          uint64_t bits = rwt[w];
+          if (bits == ~0ull) { Tt += wsum[w]; continue; }
+          for (int n = 0; bits != 0; ++n, bits >>= 4) Tt += lut[((w * 16 + n) << 4) + (unsigned)(bits & 15u)];
+        }
+      }
+    }
+    __syncthreads();
+    int ta = 0;
+    while (ta < TPB) {   // batches of whole ties with at most SP_ECAP entries (one batch, normally)
+      const unsigned ea = rps[ta];
+      int tb = TPB;
+      bool single = false;
+      if (rps[TPB] - ea > SP_ECAP) {
+        const int cnt = __syncthreads_count(tid >= ta && rps[tid + 1] - ea <= SP_ECAP);
+        single = cnt == 0;   // one tie with more entries than that: every entry is its own
+        tb = single ? ta + 1 : ta + cnt;
+      }
+      const unsigned ne = rps[tb] - ea;
+      const bool mine = tid >= ta && tid < tb;
+      if (!single) {
+        const unsigned n = mine ? r1 - r0 : 0u;
+        if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[r0 - ea + q] = (unsigned char)tid;
+        uint64_t hm = __ballot(n > 16u);
+        while (hm) {
+          const int hl = __builtin_ctzll(hm);
+          hm &= hm - 1;
+          const unsigned s_h = __builtin_amdgcn_readlane((int)(r0 - ea), hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
+          for (unsigned q = lane; q < n_h; q += 64) owner[s_h + q] = (unsigned char)(wave_base | hl);
+        }
+        __syncthreads();
+      }
+      if (UPDATE) {
+        for (unsigned q0 = wave_base; q0 < ne; q0 += TPB) {   // wave-uniform trips
+          const unsigned q = q0 + lane;
+          const bool v = q < ne;
+          const unsigned ent = v ? El[(size_t)ea + q] : 0u;
+          const int ow = single ? ta : (v ? (int)owner[q] : -1);
+          const int m = ENT_M(ent);
+          const double dx = (double)ENT_X(ent), lt = lth[m];
+          double U[K];
+          if (MUT) {
+            double w[K], cy[K];
+            weights<K>(w, cy, ct, m, ENT_Y(ent));
+#pragma unroll
+            for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * (dx * w[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
+          }
+          const int o0 = __builtin_amdgcn_readfirstlane(ow);
+          if (__all(ow == o0 || !v)) {   // the whole wave is inside one tie: reduce, then one add per k
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const double s = wave_sum(v ? U[k] : 0.0);
+              if (lane == 0) atomicAdd(&ut[o0 * K + k], s);
+            }
+          } else if (v) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
+          }
+        }
+        __syncthreads();
+        if (mine) {
+          double sum = 0.0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            r[k] = exp((lp[k] + ut[tid * K + k]) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
+            sum += r[k];
+          }
+          if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
+#pragma unroll
+            for (int k = 0; k < K; ++k) r[k] /= sum;
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            if (act) { rl[t * K + k] = r[k]; accF[k] += rowfull ? r[k] : 0.0; }
+            rt[tid * K + k] = r[k];
+            if (ELBO) ut[tid * K + k] = exp(r[k]);   // exp(rho), model.py:971 (U is consumed)
+          }
+        }
+        if (a.do_hist || ELBO) __syncthreads();
+      }
+      if (a.do_hist || ELBO) {   // walk 2: H of the (new) rho; ELBO log terms
+        for (unsigned q0 = wave_base; q0 < ne; q0 += TPB) {
+          const unsigned q = q0 + lane;
+          if (q < ne) {
+            const unsigned ent = El[(size_t)ea + q];
+            const int ow = single ? ta : (int)owner[q];
+            const int m = ENT_M(ent);
+            const unsigned y = ENT_Y(ent);
+            const double dx = (double)ENT_X(ent);
+            if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + ow * K, (unsigned)g.hc);
+            if (ELBO) {
+              double inner = 0.0;
+              if (ENT_INR(ent)) {
+                const double z2 = gnu * (double)y, gt = Gth[m];
+                const double* er = ut + ow * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+              }
+              e_log += dx * log(inner + eps);
+            }
+          }
+        }
+      }
+      if (ELBO && mine && act) {
+        double sr = 0.0, se = 0.0, en = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          sr += r[k]; se += r[k] * Ela[k];
+          en += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
+        }
+        e_lin += en - se * Tt;
+        if (MUT) e_q += sr * (double)qt;
+      }
+      ta = tb;
+      if (ta < TPB) __syncthreads();   // owner[] is rewritten by the next batch
+    }
+    __syncthreads();
+  }
+  if (a.do_hist) hist_flush(Hc, Hl, nHc);
+  if (UPDATE) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double v = block_sum(accF[k], red);
+      if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
+    }
+  }
+  if (ELBO) {
+    double v1 = block_sum(e_lin, red);
+    double v2 = block_sum(e_log, red);
+    double v3 = block_sum(e_q, red);
+    if (tid == 0) {
+      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // H summed over its NH copies
 __device__ __forceinline__ double h_at(const double* Hl0, size_t copy_stride, size_t idx) {
@@ -1351,6 +1761,11 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
   return n + 16;
 }
 
+static size_t shmem_sp(const Geo& g, bool mut, bool elbo, bool hist) {
+  return (size_t)g.Mp * 8 + (mut ? (size_t)g.Mp * g.K * 8 : 0) + 2 * (size_t)TPB * g.K * 8 + 64 + (size_t)g.W * 8 +
+         (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB + 2) * 4 + SP_ECAP;
+}
+
 struct Prof {
   vmr_ctx* h; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
   Prof(vmr_ctx* h_, int c, hipStream_t st_ = nullptr) : h(h_), cls(c), st(st_ ? st_ : h_->stream) {
@@ -1391,7 +1806,7 @@ struct Prof {
 // Opt in to > 48 KB of dynamic LDS and size the (persistent) grid to what is resident at once:
 // workgroups per layer = resident workgroups per CU x CUs / L, never more than tile pairs.
 template <class Kern>
-static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
+static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl, long long cap = 0) {
   const void* fn = reinterpret_cast<const void*>(k);
   int per_cu = 0;
   for (auto& e : h->occ) if (e.first == fn) per_cu = e.second;
@@ -1403,7 +1818,8 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
   }
   long long gl_ = (long long)per_cu * h->ncu / h->g.L;
   if (gl_ < 1) gl_ = 1;
-  if (gl_ > h->g.P) gl_ = h->g.P;
+  if (cap <= 0) cap = h->g.P;
+  if (gl_ > cap) gl_ = cap;
   *gl = (int)gl_;
   return VMR_OK;
 }
@@ -1412,7 +1828,16 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl) {
 static int launch_hist(vmr_ctx* h) {
   const Geo& g = h->g;
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
-  {
+  if (h->sparse) {
+    Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
+    SpArgs a{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
+             1, h->all_full, 1};
+    const size_t sm = shmem_sp(g, false, false, true);
+    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
+    int rc = VMR_OK;
+    DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sm, &a.Gl, NB))) return rc;
+               hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
+  } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     HistArgs a{h->X, h->rho, h->Hg, 1};
     size_t sm = shmem_hist(g);
@@ -1445,10 +1870,10 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
     switch (g.W >= 4 ? 4 : g.W) {
-      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
-      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
-      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
-      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->slotA, skip_full, g)); break;
+      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
+      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
+      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
+      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
     }
   }
   if (ms != h->stream) {
@@ -1489,7 +1914,22 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   int rc = VMR_OK;
   if (mode != 2 && g.fuse_full) HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   if (mode != 2 && !g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
-  {
+  if (h->sparse) {
+    Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
+    SpArgs s{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
+             1, h->all_full, (mode != 2 && !g.two_pass) ? 1 : 0};
+    const size_t ssm = shmem_sp(g, g.mut != 0, mode != 0, s.do_hist != 0);
+    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
+#define LSP(MUT_, UPD_, ELB_)                                                                  \
+  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_>, ssm, &s.Gl, NB))) return rc; \
+             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_>), dim3(g.L * s.Gl), blk, ssm, h->stream, s, g))
+    if (g.mut) {
+      if (mode == 0) { LSP(true, true, false); } else if (mode == 1) { LSP(true, true, true); } else { LSP(true, false, true); }
+    } else {
+      if (mode == 0) { LSP(false, true, false); } else if (mode == 1) { LSP(false, true, true); } else { LSP(false, false, true); }
+    }
+#undef LSP
+  } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
   DISPATCH_KP(g.K, g.pf, if ((rc = grid_per_layer(h, k_rho<KK, MUT_, UPD_, ELB_, PP>, sm, &a.Gl))) return rc; \
@@ -1592,12 +2032,13 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipMalloc(&h->Rb, (rows + slack) * g.W * 8));
   CCHK(hipMemsetAsync(h->Rb + rows * g.W, 0, slack * g.W * 8, h->stream));
   CCHK(hipMalloc(&h->cov, rows));
+  CCHK(hipMalloc(&h->rcls, rows));
   CCHK(hipMalloc(&h->sumx, 8));
   CCHK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
   CCHK(hipMalloc(&h->xmax, 4));
   CCHK(hipMemsetAsync(h->xmax, 0, 4, h->stream));
-  CCHK(hipMalloc(&h->npartial, 8));
-  CCHK(hipMemsetAsync(h->npartial, 0, 8, h->stream));
+  CCHK(hipMalloc(&h->npartial, 16));
+  CCHK(hipMemsetAsync(h->npartial, 0, 16, h->stream));
   {
     uint8_t* tmp = nullptr;
     const uint8_t* src = X;
@@ -1610,7 +2051,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     if (R && !data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
     hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
     CCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
+    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->rcls, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
     CCHK(hipGetLastError());
     CCHK(hipStreamSynchronize(h->stream));
     if (tmp) CCHK(hipFree(tmp));
@@ -1628,31 +2069,104 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     unsigned xm = 0;
     CCHK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
     CCHK(hipMemcpy(&h->n_partial, h->npartial, 8, hipMemcpyDeviceToHost));
-    g.fuse_full = (g.W <= 4) ? 1 : 0;
+    g.fuse_full = 1;
     CCHK(hipMalloc(&h->slotF, (size_t)L * NSLOT * K * 8));
     CCHK(hipMemsetAsync(h->slotF, 0, (size_t)L * NSLOT * K * 8, h->stream));
     g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
+    {
+      unsigned long long np2[2] = {0, 0};
+      CCHK(hipMemcpy(np2, h->npartial, 16, hipMemcpyDeviceToHost));
+      h->all_full = (np2[0] == 0 && np2[1] == 0) ? 1 : 0;
+    }
+    // ---- data format: report lists unless X is dense enough that 1 B per (tie, reporter) is less to read ----
+    {
+      const size_t T = (size_t)N * N;
+      const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
+      const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
+      if (!force_dense && g.Mp <= 8192) {
+        CCHK(hipMalloc(&h->rp, (size_t)L * (T + 1) * 4));
+        unsigned long long* nnz_dev = nullptr;
+        CCHK(hipMalloc(&nnz_dev, (size_t)L * 8));
+        CCHK(hipMemsetAsync(nnz_dev, 0, (size_t)L * 8, h->stream));
+        const unsigned cgrid = (unsigned)std::min<size_t>(8192, (T + 15) / 16);
+        for (int l = 0; l < L; ++l)
+          hipLaunchKernelGGL(k_sp_count, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                             h->rp + (size_t)l * (T + 1), nnz_dev + l, T, g.Mp);
+        CCHK(hipGetLastError());
+        CCHK(hipStreamSynchronize(h->stream));   // the stream is non-blocking: a plain hipMemcpy does not wait for it
+        std::vector<unsigned long long> nl(L), eb(L);
+        CCHK(hipMemcpy(nl.data(), nnz_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
+        CCHK(hipFree(nnz_dev));
+        bool fits = true;
+        h->nnz = 0;
+        for (int l = 0; l < L; ++l) { eb[l] = h->nnz; h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
+        const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
+        h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
+        if (h->sparse) {
+          const size_t n = T + 1;
+          const unsigned nbs = (unsigned)((n + 2047) / 2048);
+          unsigned* bsum = nullptr;
+          CCHK(hipMalloc(&bsum, (size_t)nbs * 4));
+          for (int l = 0; l < L; ++l) {
+            unsigned* rpl = h->rp + (size_t)l * n;
+            hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
+            hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs);
+            hipLaunchKernelGGL(k_scan_add, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
+          }
+          CCHK(hipGetLastError());
+          CCHK(hipMalloc(&h->ebase, (size_t)L * 8));
+          CCHK(hipMemcpyAsync(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
+          CCHK(hipMalloc(&h->E, ((size_t)h->nnz + 64) * 4));
+          CCHK(hipMalloc(&h->Qt, rows * 4));
+          CCHK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
+          for (int l = 0; l < L; ++l) {
+            if (g.mut)
+              hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->E + eb[l], h->Qt + (size_t)l * T, g);
+            else
+              hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->E + eb[l], h->Qt + (size_t)l * T, g);
+          }
+          CCHK(hipGetLastError());
+          CCHK(hipStreamSynchronize(h->stream));
+          CCHK(hipFree(bsum));
+          if (!getenv("VMR_KEEP_X")) { CCHK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
+        } else {
+          CCHK(hipFree(h->rp));
+          h->rp = nullptr;
+        }
+      } else if (force_sparse) {
+        vmr_destroy(h);
+        return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192");
+      }
+    }
     // LDS levels of H (mirror counts 0..hc-1; higher counts are rare and go to global atomics, which are slow
     // for scattered 8-byte adds): all of min(Y, HC_MAX) must fit.  Beside the rho pass' tables when that keeps
-    // >= 2 workgroups per CU resident (one pass per sweep); otherwise in k_hist alone (two passes per sweep).
+    // >= 2 workgroups per CU resident (one pass per sweep); otherwise in the statistics pass alone (two passes).
     g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
     g.two_pass = 0;
-    if (shmem_rho(g, true, false) > 80000) {
-      g.two_pass = 1;
-      while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
-    }
-    // the rho pass keeps per-reporter tables in LDS (G_theta, the mutuality weights c[m,k], and log G_theta
-    // for the ELBO variant): (K + 2) * 8 bytes per reporter beside the tile pair.  160 KB per workgroup on gfx950.
-    {
-      size_t need = shmem_rho(g, true, true);
-      if (shmem_hist(g) > need) need = shmem_hist(g);
-      if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
-        char msg[256];
-        snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
-                 "reduce M or K", M, K, g.mut ? " and mutuality" : "", need, 160 * 1024);
-        vmr_destroy(h);
-        return fail(nullptr, VMR_EINVAL, msg);
+    size_t need = 0;
+    if (h->sparse) {
+      if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
+        g.two_pass = 1;
+        while (g.hc > 0 && shmem_sp(g, false, false, true) > 160000) --g.hc;
       }
+      need = std::max(shmem_sp(g, g.mut != 0, true, !g.two_pass), shmem_sp(g, false, false, true));
+    } else {
+      if (shmem_rho(g, true, false) > 80000) {
+        g.two_pass = 1;
+        while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
+      }
+      need = std::max(shmem_rho(g, true, true), shmem_hist(g));
+    }
+    // per-reporter tables live in LDS (E[log theta], the mutuality weights c[m,k], G_theta for the ELBO):
+    // (K + 2) * 8 bytes per reporter.  160 KB per workgroup on gfx950.
+    if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
+      char msg[256];
+      snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
+               "reduce M or K", M, K, g.mut ? " and mutuality" : "", need, 160 * 1024);
+      vmr_destroy(h);
+      return fail(nullptr, VMR_EINVAL, msg);
     }
     CCHK(hipMalloc(&h->Hg, (size_t)L * NH * g.Y * g.Mp * K * 8));
     CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
@@ -1671,7 +2185,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->E, h->rp, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1922,11 +2436,33 @@ int vmr_profile_read(vmr_handle h, int kernel_class, double* total_ms, int64_t* 
   return VMR_OK;
 }
 
+int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz) {
+  if (!h) return VMR_EINVAL;
+  if (sparse) *sparse = h->sparse;
+  if (nnz) *nnz = h->nnz;
+  return VMR_OK;
+}
+
 int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   if (!h || !bytes) return VMR_EINVAL;
   const Geo& g = h->g;
   const double V = (double)g.L * g.N * g.N * g.M;   // canonical: X 1 B/elt, R 1 bit/elt
   const double SX = V, SR = V / 8.0, Srho = 8.0 * g.L * (double)g.N * g.N * g.K;
+  if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
+    const double ties = (double)g.L * g.N * g.N;
+    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties + g.L);
+    const double mask = h->all_full ? 0.0 : ties + (double)h->n_partial * g.W * 8.0;
+    const double Q = g.mut ? 4.0 * ties : 0.0;
+    switch (kernel_class) {
+      case VMR_KERNEL_GAMMA_MASK: *bytes = ties + (double)h->n_partial * g.W * 8.0 + Srho; break;
+      case VMR_KERNEL_GAMMA_COUNTS: *bytes = E + RP + Srho; break;
+      case VMR_KERNEL_RHO: *bytes = E + RP + mask + 2.0 * Srho; break;
+      case VMR_KERNEL_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;
+      case VMR_KERNEL_RHO_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;
+      default: *bytes = 0.0; break;
+    }
+    return VMR_OK;
+  }
   switch (kernel_class) {
     case VMR_KERNEL_GAMMA_MASK: *bytes = SR + Srho; break;
     case VMR_KERNEL_GAMMA_COUNTS: *bytes = SX + Srho; break;   // statistics pass (once per realisation)

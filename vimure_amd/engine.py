@@ -165,6 +165,12 @@ class CaviEngine:
                                                C.addressof(gc)))
         return gt, gl, gn.value, gc.value
 
+    def data_format(self):
+        """("sparse" | "dense", non-zero counts in X): the layout vmr_create chose for this dataset."""
+        sp, nnz = C.c_int(), C.c_uint64()
+        self._check(self.lib.vmr_data_format(self._h, C.byref(sp), C.byref(nnz)))
+        return ("sparse" if sp.value else "dense"), int(nnz.value)
+
     # -- measurement
     def profile(self, enable=True):
         self._check(self.lib.vmr_profile(self._h, int(enable)))
