@@ -85,8 +85,8 @@ def test_m7000_tile_edge1_chunk_walk():
     _run(L=1, N=20, M=7000, K=2, eta=0.0, mutuality=False, mask="ones", sweeps=2)      # b = 1, 64 lanes per tie
 
 
-def test_m4500_mutuality_tables_fill_lds():
-    _run(L=1, N=24, M=4500, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2)     # ~155 KB of LDS tables
+def test_m4000_mutuality_tables_fill_lds():
+    _run(L=1, N=24, M=4000, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2)     # ~150 KB of LDS tables
 
 
 def test_reporter_tables_beyond_lds_are_refused():

@@ -64,7 +64,8 @@ struct Geo {
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
   int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
-  int dbg;      // timing experiments only (env VMR_DEBUG): 1 = skip per-report math, 2 = skip the scan
+  int dbg;      // timing experiments only (env VMR_DEBUG; results are wrong): dense path 1 = skip per-report math, 2 = skip
+                // the scan; report lists 8 = no H flush, 16 = no walk 2, 32 = no walk 1, 64 = no owner map, 128 = no per-tie update
   double eps;
 };
 
@@ -363,6 +364,28 @@ __device__ __forceinline__ void weights(double (&w)[K], double (&cy)[K], const d
     cy[k] = c * dy;
     const double r = fast_rcp(1.0 + cy[k]);
     w[k] = (y == 0) ? ((c < (double)INFINITY) ? 1.0 : 0.0) : r;
+  }
+}
+
+// the same weights from cb = G_nu / G_theta_m and 1 / G_lambda_k (report lists: one table entry per reporter)
+template <int K>
+__device__ __forceinline__ void weights_cb(double (&w)[K], double cb, const double (&iGla)[K], unsigned y) {
+  const double dy = (double)y;
+  double c[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) c[k] = cb * iGla[k];
+  if (K == 2) {   // one reciprocal for both categories: 1/a0 = a1/(a0 a1)
+    if (c[0] < (double)INFINITY && c[1] < (double)INFINITY) {
+      const double a0 = 1.0 + c[0] * dy, a1 = 1.0 + c[1] * dy;
+      const double r = fast_rcp(a0 * a1);
+      w[0] = a1 * r; w[1] = a0 * r;   // y = 0: a0 = a1 = 1 and r = 1 exactly
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double r = fast_rcp(1.0 + c[k] * dy);
+    w[k] = (y == 0) ? ((c[k] < (double)INFINITY) ? 1.0 : 0.0) : r;
   }
 }
 
@@ -749,7 +772,10 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 // ([L][Y][Mp][K] doubles, Y = max count + 1); mirror counts 0..HC-1 are accumulated in LDS, the rest with global
 // f64 atomics.  k_hist builds H from the current rho (start of a fit, sub-step tests).
 // ------------------------------------------------------------------------------------------
-#define NH 8       // copies of H in global memory (workgroup gb adds into copy gb % NH): spreads the atomics
+#ifndef NH
+#define NH 8
+#endif
+// NH copies of H in global memory (workgroup gb adds into copy gb % NH): spreads the atomics
 #define HC_MAX 3   // mirror-count levels cached in LDS when they fit (93 % of the reports at BASELINE config 3); Geo.hc
 
 struct HistArgs {
@@ -1122,7 +1148,11 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 // instead of the 1 B per (tie, reporter) of the dense layout, and no tile pair has to be staged: 4.5 GB -> 1.2 GB
 // per sweep at BASELINE config 3.  The dense tensor is freed once the lists exist.
 // ==========================================================================================
-#define SP_ECAP 4096   // entries of a batch whose owners are resolved through LDS
+#define SP_ECAP 1024   // entries of a wave's step (64 ties) whose owners are resolved through its LDS map
+#ifndef SP_PF
+#define SP_PF 4
+#endif
+// SP_PF: entries per lane that are prefetched one step ahead (the first SP_PF*64 of a step)
 #define ENT_M(e) ((int)((e) & 0x1fffu))
 #define ENT_INR(e) (((e) >> 13) & 1u)
 #define ENT_X(e) (((e) >> 16) & 0xffu)
@@ -1266,35 +1296,52 @@ struct SpArgs {
 };
 
 // rho update (UPDATE), ELBO data terms (ELBO) and the statistics H (a.do_hist) from the report lists.
-// A workgroup takes 256 consecutive ties per step, one per thread for the per-tie work (log prior, mask sum T,
-// exp / normalise, write-back); their entries are one contiguous run of the list and are walked entry-parallel
-// (coalesced 4-byte loads, thread <-> entry); owner[] maps an entry to its tie (filled by the tie's thread; long
-// runs by the whole wave).  Walk 1 gathers U_k per tie with LDS atomics, walk 2 (after the per-tie update) adds
-// x * rho_new into H and collects the ELBO's log terms.
+// A WAVE takes 64 consecutive ties per step, one per lane for the per-tie work (log prior, mask sum T, exp /
+// normalise, write-back); their entries are one contiguous run of the list and are walked entry-parallel
+// (coalesced 4-byte loads, lane <-> entry); owner[] maps an entry to its tie (filled by the tie's lane; long runs
+// by the whole wave).  Walk 1 gathers U_k per tie with LDS atomics, walk 2 (after the per-tie update) adds
+// x * rho_new into H and collects the ELBO's log terms.  The waves of a workgroup share only the read-only tables
+// and the LDS levels of H, so the step loop has no workgroup barrier: waves drift apart and cover each other's
+// memory latency; the next step's values and entries are prefetched into registers.
+// Orders a wave's LDS traffic across lanes: the LDS executes one wave's operations in issue order, so all that is
+// needed is that the compiler keeps them in program order.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <int K, bool MUT, bool UPDATE, bool ELBO>
 __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   size_t off = 0;
-  double* lth = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * 8;
-  double* ct = reinterpret_cast<double*>(smem + off); off += MUT ? (size_t)g.Mp * K * 8 : 0;
-  double* ut = reinterpret_cast<double*>(smem + off); off += (size_t)TPB * K * 8;   // U per tie; exp(rho) in the ELBO walk
-  double* rt = reinterpret_cast<double*>(smem + off); off += (size_t)TPB * K * 8;   // (new) rho per tie
+  // per reporter: E[log theta_m] and, with mutuality, cb_m = G_nu / G_theta_m beside it (one 16-byte LDS read per
+  // report; the weight's c[m,k] = G_nu / (G_theta_m G_lambda_k) = cb_m / G_lambda_k)
+  double* tb = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * (MUT ? 16 : 8);
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   const int nHc = a.do_hist ? g.hc * g.Mp * K : 0;
   double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;
   double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
-  unsigned* rps = reinterpret_cast<unsigned*>(smem + off); off += (size_t)(TPB + 2) * 4;
-  unsigned char* owner = smem + off;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // entry slot of a lane within a 64-entry trip: the (usually 2-8) consecutive entries of one tie go to lanes 32 / 16 / 48
+  // apart, i.e. to different LDS service groups, so their adds to the tie's sum do not collide on one address
+  const unsigned pl = ((unsigned)(lane & 15) << 2) | ((unsigned)(lane >> 5) & 1u) | ((((unsigned)lane >> 4) & 1u) << 1);
+  // wave-private: per-tie sums (U, then the tie's new rho; ELBO variants: exp(rho), and rho in rt) and the owner map
+  double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)TPB * K * 8;
+  double* rt = ELBO ? reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K : ut; off += ELBO ? (size_t)TPB * K * 8 : 0;
+  unsigned char* owner = smem + off + (size_t)wv * SP_ECAP;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const size_t T = (size_t)g.N * g.N;
-  const long long NB = (long long)((T + TPB - 1) / TPB);
-  const long long b0 = (long long)gb * NB / a.Gl, b1 = (long long)(gb + 1) * NB / a.Gl;
+  const long long NS = (long long)((T + 63) / 64);   // steps of 64 ties; a workgroup owns a contiguous range, its waves interleave
+  const long long s0 = (long long)gb * NS / a.Gl, s1 = (long long)(gb + 1) * NS / a.Gl;
+  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
   for (int m = tid; m < g.Mp; m += TPB) {
-    lth[m] = a.par[o.l_th + (size_t)l * g.Mp + m];
-    if (ELBO) Gth[m] = a.par[o.G_th + (size_t)l * g.Mp + m];
+    const double lt_ = a.par[o.l_th + (size_t)l * g.Mp + m], gt_ = a.par[o.G_th + (size_t)l * g.Mp + m];
+    if (MUT) { tb[2 * m] = lt_; tb[2 * m + 1] = (gt_ == 0.0) ? (double)INFINITY : gnu / gt_; }
+    else tb[m] = lt_;
+    if (ELBO) Gth[m] = gt_;
   }
   for (int q = tid; q < nHc; q += TPB) Hc[q] = 0.0;
   const double* lut = a.lutg + (size_t)l * g.W * 256;
@@ -1308,13 +1355,14 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   for (int k = 0; k < K; ++k) {
     Ela[k] = a.par[o.E_la + l * K + k]; lla[k] = a.par[o.l_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k];
   }
-  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  double iGla[K];   // 1 / G_lambda_k (inf when it underflowed: the weight is then 0, the reference's den == 0 rule)
+#pragma unroll
+  for (int k = 0; k < K; ++k) iGla[k] = (Gla[k] == 0.0) ? (double)INFINITY : 1.0 / Gla[k];
   const double eps = g.eps;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
-  if (MUT) build_ct<K>(ct, a.par + o.G_th + (size_t)l * g.Mp, Gla, gnu, g.Mp);
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
   const unsigned* rpl = a.rp + (size_t)l * (T + 1);
   const unsigned* El = a.E + a.ebase[l];
@@ -1324,10 +1372,20 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   double* rl = a.rho + (size_t)l * T * K;
   const double* lpl = a.logpr + (size_t)l * T * K;
 
+  // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 entries of
+  // the wave's next step and the entry range of the one after are in flight.
   unsigned r0n = 0, r1n = 0, clsn = 0, qn = 0;
   double lpn[K], rn[K];
-  auto fetch_tie = [&](long long blk) {
-    const size_t t = (size_t)blk * TPB + tid;
+  unsigned pen[SP_PF];
+  unsigned ea1 = 0, eb1 = 0, ea2 = 0, eb2 = 0;
+  auto fetch_range = [&](long long s, unsigned& ea, unsigned& eb) {
+    const size_t t0 = (size_t)s * 64;
+    const size_t t1 = t0 + 64 < T ? t0 + 64 : T;
+    ea = rpl[t0 < T ? t0 : T];
+    eb = rpl[t1];
+  };
+  auto fetch_tie = [&](long long s, unsigned ea, unsigned eb) {
+    const size_t t = (size_t)s * 64 + lane;
     const bool ok = t < T;
     r0n = rpl[ok ? t : T];
     r1n = rpl[ok ? t + 1 : T];
@@ -1338,27 +1396,60 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
       lpn[k] = ((UPDATE || ELBO) && ok) ? lpl[t * K + k] : 0.0;
       rn[k] = (!UPDATE && ok) ? rl[t * K + k] : 0.0;
     }
+#pragma unroll
+    for (int j = 0; j < SP_PF; ++j) {
+      const unsigned q = pl + (unsigned)j * 64;
+      unsigned v = 0u;
+      if (q < eb - ea) v = El[(size_t)ea + q];
+      pen[j] = v;
+    }
   };
-  if (b0 < b1) fetch_tie(b0);
-  __syncthreads();
+  const long long sfirst = s0 + wv;
+  if (sfirst < s1) {
+    fetch_range(sfirst, ea1, eb1);
+    if (sfirst + TPB / 64 < s1) fetch_range(sfirst + TPB / 64, ea2, eb2);
+    fetch_tie(sfirst, ea1, eb1);
+  }
+  __syncthreads();   // tables
   double Tfull = 0.0;
   for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
 
-  for (long long blk = b0; blk < b1; ++blk) {
-    const size_t t = (size_t)blk * TPB + tid;
+  for (long long s = sfirst; s < s1; s += TPB / 64) {
+    const size_t t = (size_t)s * 64 + lane;
     const bool act = t < T;
     const unsigned r0 = r0n, r1 = r1n, cls = clsn, qt = qn;
+    const unsigned ea = ea1, ne = eb1 - ea1;
     double lp[K], r[K];
+    unsigned pe[SP_PF];
 #pragma unroll
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
-    rps[tid] = r0;
-    if (tid == TPB - 1) rps[TPB] = r1;
+#pragma unroll
+    for (int j = 0; j < SP_PF; ++j) pe[j] = pen[j];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (UPDATE) ut[tid * K + k] = 0.0;
-      else { rt[tid * K + k] = r[k]; if (ELBO) ut[tid * K + k] = exp(r[k]); }
+      if (UPDATE) ut[lane * K + k] = 0.0;
+      else { rt[lane * K + k] = r[k]; if (ELBO) ut[lane * K + k] = exp(r[k]); }
     }
-    if (blk + 1 < b1) fetch_tie(blk + 1);   // in flight while this step is processed
+    // owner[]: the tie (lane) of every entry; a tie's lane fills its run, long runs are filled by the whole wave
+    auto build_owner = [&](unsigned e_first, bool mine) {
+      const unsigned n = mine ? r1 - r0 : 0u;
+      if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[r0 - e_first + q] = (unsigned char)lane;
+      uint64_t hm = __ballot(n > 16u);
+      while (hm) {
+        const int hl = __builtin_ctzll(hm);
+        hm &= hm - 1;
+        const unsigned s_h = __builtin_amdgcn_readlane((int)(r0 - e_first), hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
+        for (unsigned q = lane; q < n_h; q += 64) owner[s_h + q] = (unsigned char)hl;
+      }
+    };
+    const bool fast = ne <= SP_ECAP;   // the step's entries fit the owner map (always, in practice)
+    if (fast && !(g.dbg & 64)) build_owner(ea, true);
+    // next steps' loads
+    ea1 = ea2; eb1 = eb2;
+    if (s + TPB / 64 < s1) {
+      if (s + 2 * (TPB / 64) < s1) fetch_range(s + 2 * (TPB / 64), ea2, eb2);
+      fetch_tie(s + TPB / 64, ea1, eb1);
+    }
     double Tt = 0.0;
     bool rowfull = false;
     if (UPDATE || ELBO) {   // T = sum_m R E[theta_m] (model.py:766-792)
@@ -1372,121 +1463,150 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
         }
       }
     }
-    __syncthreads();
-    int ta = 0;
-    while (ta < TPB) {   // batches of whole ties with at most SP_ECAP entries (one batch, normally)
-      const unsigned ea = rps[ta];
-      int tb = TPB;
-      bool single = false;
-      if (rps[TPB] - ea > SP_ECAP) {
-        const int cnt = __syncthreads_count(tid >= ta && rps[tid + 1] - ea <= SP_ECAP);
-        single = cnt == 0;   // one tie with more entries than that: every entry is its own
-        tb = single ? ta + 1 : ta + cnt;
-      }
-      const unsigned ne = rps[tb] - ea;
-      const bool mine = tid >= ta && tid < tb;
-      if (!single) {
-        const unsigned n = mine ? r1 - r0 : 0u;
-        if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[r0 - ea + q] = (unsigned char)tid;
-        uint64_t hm = __ballot(n > 16u);
-        while (hm) {
-          const int hl = __builtin_ctzll(hm);
-          hm &= hm - 1;
-          const unsigned s_h = __builtin_amdgcn_readlane((int)(r0 - ea), hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
-          for (unsigned q = lane; q < n_h; q += 64) owner[s_h + q] = (unsigned char)(wave_base | hl);
+    wave_sync();   // everything below is wave-local: LDS operations of a wave complete in order
+
+    auto walk1 = [&](unsigned e_first, unsigned nb_, bool pf, int single_tie) {
+      const int trips = (int)((nb_ + 63) / 64);
+      auto body = [&](unsigned ent, bool v, unsigned q) {
+        const int ow = single_tie >= 0 ? single_tie : (v ? (int)owner[q] : -1);
+        const int m = ENT_M(ent);
+        const double dx = (double)ENT_X(ent);
+        double U[K];
+        if (MUT) {
+          const double2 te = *reinterpret_cast<const double2*>(tb + 2 * m);
+          double w[K];
+          weights_cb<K>(w, te.y, iGla, ENT_Y(ent));
+#pragma unroll
+          for (int k = 0; k < K; ++k) U[k] = (te.x + lla[k]) * (dx * w[k]);
+        } else {
+          const double lt = tb[m];
+#pragma unroll
+          for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
         }
-        __syncthreads();
+        const int o0 = __builtin_amdgcn_readfirstlane(ow);
+        if (__all(ow == o0 || !v)) {   // the whole wave is inside one tie: reduce, then one add per k
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const double sm_ = wave_sum(v ? U[k] : 0.0);
+            if (lane == 0) atomicAdd(&ut[o0 * K + k], sm_);
+          }
+        } else if (v) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < SP_PF; ++j) {
+        const unsigned q = pl + (unsigned)j * 64;
+        if ((unsigned)j * 64 < nb_) {   // wave-uniform
+          const bool v = q < nb_;
+          body(pf ? pe[j] : (v ? El[(size_t)e_first + q] : 0u), v, q);
+        }
       }
+      for (int j = SP_PF; j < trips; ++j) {
+        const unsigned q = pl + (unsigned)j * 64;
+        const bool v = q < nb_;
+        body(v ? El[(size_t)e_first + q] : 0u, v, q);
+      }
+    };
+    auto walk2 = [&](unsigned e_first, unsigned nb_, bool pf, int single_tie) {
+      const int trips = (int)((nb_ + 63) / 64);
+      auto body = [&](unsigned ent, unsigned q) {
+        const int ow = single_tie >= 0 ? single_tie : (int)owner[q];
+        const int m = ENT_M(ent);
+        const unsigned y = ENT_Y(ent);
+        const double dx = (double)ENT_X(ent);
+        if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + ow * K, (unsigned)g.hc);
+        if (ELBO) {
+          double inner = 0.0;
+          if (ENT_INR(ent)) {
+            const double z2 = gnu * (double)y, gt = Gth[m];
+            const double* er = ut + ow * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+          }
+          e_log += dx * log(inner + eps);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < SP_PF; ++j) {
+        const unsigned q = pl + (unsigned)j * 64;
+        if (q < nb_) body(pf ? pe[j] : El[(size_t)e_first + q], q);
+      }
+      for (int j = SP_PF; j < trips; ++j) {
+        const unsigned q = pl + (unsigned)j * 64;
+        if (q < nb_) body(El[(size_t)e_first + q], q);
+      }
+    };
+    auto update_tie = [&](bool mine) {   // per-tie update from the finished sums
+      if (!mine) return;
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        r[k] = exp((lp[k] + ut[lane * K + k]) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
+        sum += r[k];
+      }
+      if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] /= sum;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (act) { rl[t * K + k] = r[k]; accF[k] += rowfull ? r[k] : 0.0; }
+        if (ELBO) { rt[lane * K + k] = r[k]; ut[lane * K + k] = exp(r[k]); }   // exp(rho), model.py:971 (U is consumed)
+        else ut[lane * K + k] = r[k];                                          // rt aliases ut
+      }
+    };
+    auto elbo_tie = [&](bool mine) {
+      if (!(ELBO && mine && act)) return;
+      double sr = 0.0, se = 0.0, en = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        sr += r[k]; se += r[k] * Ela[k];
+        en += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
+      }
+      e_lin += en - se * Tt;
+      if (MUT) e_q += sr * (double)qt;
+    };
+
+    if (fast) {
       if (UPDATE) {
-        for (unsigned q0 = wave_base; q0 < ne; q0 += TPB) {   // wave-uniform trips
-          const unsigned q = q0 + lane;
-          const bool v = q < ne;
-          const unsigned ent = v ? El[(size_t)ea + q] : 0u;
-          const int ow = single ? ta : (v ? (int)owner[q] : -1);
-          const int m = ENT_M(ent);
-          const double dx = (double)ENT_X(ent), lt = lth[m];
-          double U[K];
-          if (MUT) {
-            double w[K], cy[K];
-            weights<K>(w, cy, ct, m, ENT_Y(ent));
-#pragma unroll
-            for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * (dx * w[k]);
-          } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
-          }
-          const int o0 = __builtin_amdgcn_readfirstlane(ow);
-          if (__all(ow == o0 || !v)) {   // the whole wave is inside one tie: reduce, then one add per k
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const double s = wave_sum(v ? U[k] : 0.0);
-              if (lane == 0) atomicAdd(&ut[o0 * K + k], s);
-            }
-          } else if (v) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
-          }
-        }
-        __syncthreads();
-        if (mine) {
-          double sum = 0.0;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            r[k] = exp((lp[k] + ut[tid * K + k]) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
-            sum += r[k];
-          }
-          if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
-#pragma unroll
-            for (int k = 0; k < K; ++k) r[k] /= sum;
-          }
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            if (act) { rl[t * K + k] = r[k]; accF[k] += rowfull ? r[k] : 0.0; }
-            rt[tid * K + k] = r[k];
-            if (ELBO) ut[tid * K + k] = exp(r[k]);   // exp(rho), model.py:971 (U is consumed)
-          }
-        }
-        if (a.do_hist || ELBO) __syncthreads();
+        if (!(g.dbg & 32)) walk1(ea, ne, true, -1);
+        wave_sync();
+        if (!(g.dbg & 128)) update_tie(true);
+        wave_sync();
       }
-      if (a.do_hist || ELBO) {   // walk 2: H of the (new) rho; ELBO log terms
-        for (unsigned q0 = wave_base; q0 < ne; q0 += TPB) {
-          const unsigned q = q0 + lane;
-          if (q < ne) {
-            const unsigned ent = El[(size_t)ea + q];
-            const int ow = single ? ta : (int)owner[q];
-            const int m = ENT_M(ent);
-            const unsigned y = ENT_Y(ent);
-            const double dx = (double)ENT_X(ent);
-            if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + ow * K, (unsigned)g.hc);
-            if (ELBO) {
-              double inner = 0.0;
-              if (ENT_INR(ent)) {
-                const double z2 = gnu * (double)y, gt = Gth[m];
-                const double* er = ut + ow * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
-              }
-              e_log += dx * log(inner + eps);
-            }
-          }
+      if ((a.do_hist || ELBO) && !(g.dbg & 16)) walk2(ea, ne, true, -1);
+      elbo_tie(true);
+    } else {
+      // more entries than owner[] holds: batches of whole ties (a single tie with more than SP_ECAP entries is its
+      // own batch and needs no owner map)
+      int ta = 0;
+      while (ta < 64) {   // wave-uniform
+        const unsigned e_first = (unsigned)__builtin_amdgcn_readlane((int)r0, ta);
+        const uint64_t fit = __ballot(lane >= ta && r1 - e_first <= SP_ECAP);
+        const int cnt = __popcll(fit);
+        const bool single = cnt == 0;
+        const int tb = single ? ta + 1 : ta + cnt;
+        const unsigned nb_ = (unsigned)__builtin_amdgcn_readlane((int)r1, tb - 1) - e_first;
+        const bool mine = lane >= ta && lane < tb;
+        if (!single) { build_owner(e_first, mine); wave_sync(); }
+        if (UPDATE) {
+          walk1(e_first, nb_, false, single ? ta : -1);
+          wave_sync();
+          update_tie(mine);
+          wave_sync();
         }
+        if (a.do_hist || ELBO) walk2(e_first, nb_, false, single ? ta : -1);
+        elbo_tie(mine);
+        ta = tb;
+        wave_sync();
       }
-      if (ELBO && mine && act) {
-        double sr = 0.0, se = 0.0, en = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          sr += r[k]; se += r[k] * Ela[k];
-          en += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
-        }
-        e_lin += en - se * Tt;
-        if (MUT) e_q += sr * (double)qt;
-      }
-      ta = tb;
-      if (ta < TPB) __syncthreads();   // owner[] is rewritten by the next batch
     }
-    __syncthreads();
+    wave_sync();
   }
-  if (a.do_hist) hist_flush(Hc, Hl, nHc);
+  __syncthreads();
+  if (a.do_hist && !(g.dbg & 8)) hist_flush(Hc, Hl, nHc);
   if (UPDATE) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1762,8 +1882,8 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
 }
 
 static size_t shmem_sp(const Geo& g, bool mut, bool elbo, bool hist) {
-  return (size_t)g.Mp * 8 + (mut ? (size_t)g.Mp * g.K * 8 : 0) + 2 * (size_t)TPB * g.K * 8 + 64 + (size_t)g.W * 8 +
-         (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB + 2) * 4 + SP_ECAP;
+  return (size_t)g.Mp * (mut ? 16 : 8) + (elbo ? 2 : 1) * (size_t)TPB * g.K * 8 + 64 +
+         (size_t)g.W * 8 + (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB / 64) * SP_ECAP;
 }
 
 struct Prof {
@@ -1833,7 +1953,7 @@ static int launch_hist(vmr_ctx* h) {
     SpArgs a{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
              1, h->all_full, 1};
     const size_t sm = shmem_sp(g, false, false, true);
-    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
+    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;   // at least one 64-tie step per wave
     int rc = VMR_OK;
     DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sm, &a.Gl, NB))) return rc;
                hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
