@@ -102,6 +102,9 @@ struct vmr_ctx {
   bool h_valid = false;        // H matches the current rho
   double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
   bool f_valid = false;        // slotF matches the current rho
+  bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
+  bool h_zero = false;         // k_fin_gamma consumed H and slotF: both are all zero, ready for the rho pass
+  bool fin_attr = false;
   unsigned long long* npartial = nullptr;   // rows of R that are neither empty nor all ones
   unsigned long long n_partial = 0;
   unsigned* xmax = nullptr;
@@ -776,7 +779,10 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 #define NH 8
 #endif
 // NH copies of H in global memory (workgroup gb adds into copy gb % NH): spreads the atomics
-#define HC_MAX 3   // mirror-count levels cached in LDS when they fit (93 % of the reports at BASELINE config 3); Geo.hc
+#ifndef HC_MAX
+#define HC_MAX 3
+#endif
+// HC_MAX: mirror-count levels cached in LDS when they fit (93 % of the reports at BASELINE config 3); Geo.hc
 
 struct HistArgs {
   const uint8_t* X; const double* rho; double* Hg;
@@ -811,7 +817,7 @@ struct TileIter {
 
 // one report into H: LDS cache for small mirror counts, global atomics beyond
 template <int K>
-__device__ __forceinline__ void hist_add(double* Hc, double* Hl /*layer's [Y][Mp][K]*/, int Mp, int m, unsigned y,
+__device__ __forceinline__ void hist_add(double* Hc, double* Hl /*this workgroup's copy [Y][Mp][K]*/, int Mp, int m, unsigned y,
                                          double dx, const double* r, unsigned hc) {
   if (y < hc) {
     double* d = Hc + ((size_t)y * Mp + m) * K;
@@ -1626,69 +1632,135 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// H summed over its NH copies
-__device__ __forceinline__ double h_at(const double* Hl0, size_t copy_stride, size_t idx) {
-  double v = 0.0;
+// H is accumulated in NH copies (workgroup gb adds into copy gb % NH; adding the rare high levels to one copy
+// only was tried: the rho pass ran 1.8x longer on the contended addresses).  Before anything reads it the copies
+// are folded into copy 0 by many workgroups (k_fin_rho does it on its way, k_h_reduce otherwise): one workgroup
+// per layer reading 8 x 50 KB was most of the finalize kernels' time.
+__device__ __forceinline__ double h_fold(double* Hl0, size_t copy_stride, size_t idx) {
+  double v[NH];
 #pragma unroll
-  for (int c = 0; c < NH; ++c) v += Hl0[c * copy_stride + idx];
+  for (int c = 0; c < NH; ++c) v[c] = Hl0[c * copy_stride + idx];   // all copies in flight at once
+  double t = 0.0;
+#pragma unroll
+  for (int c = 0; c < NH; ++c) {
+    t += v[c];
+    if (c > 0) Hl0[c * copy_stride + idx] = 0.0;
+  }
+  Hl0[idx] = t;
+  return t;
+}
+__global__ __launch_bounds__(TPB) void k_h_reduce(double* Hg, Geo g) {
+  const size_t hcs = (size_t)g.Y * g.Mp * g.K, n = (size_t)g.L * hcs;
+  for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < n; q += (size_t)gridDim.x * TPB) {
+    const size_t l = q / hcs, idx = q - l * hcs;
+    h_fold(Hg + l * NH * hcs, hcs, idx);
+  }
+}
+template <bool ZERO>
+__device__ __forceinline__ double h_sum(double* Hl0, size_t, size_t idx) {   // folded H: copy 0
+  const double v = Hl0[idx];
+  if (ZERO) Hl0[idx] = 0.0;
   return v;
 }
+__device__ __forceinline__ double h_at(const double* Hl0, size_t, size_t idx) { return Hl0[idx]; }
 
-// finalize kernels (one workgroup per layer / one workgroup)
+#define FIN_TPB 1024   // the finalize kernels are latency-bound chains over H: one workgroup per layer, 16 waves
+__device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) {   // result valid in thread 0
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < FIN_TPB / 64; ++w) r += red[w];
+  }
+  return r;
+}
+
+// finalize kernels (one workgroup per layer)
 // ------------------------------------------------------------------------------------------
 // gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
 // then phi_rte from the same A with the new E[theta] (model.py:742-749); mutuality off: phi_shp too.
-__global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __restrict__ Hg, double* slotA,
-                                                   const double* __restrict__ slotF, double* lutg, int do_phi, Geo g) {
-  __shared__ double red[8];
+// Threads take (y, m) items of H (coalesced, all copies in flight at once), then one thread per reporter
+// finishes gamma.  consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for
+// the rho pass that follows.
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, double* slotA, double* slotF,
+                                                       double* lutg, int do_phi, int consume, Geo g) {
+  extern __shared__ double dyn[];   // s1[Mp]: sum_{y,k} w1 H per reporter; gthn[Mp]: the new G_theta
+  double* s1 = dyn;
+  double* gthn = dyn + g.Mp;
+  __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x, K = g.K, Wp = g.W * 64;
-  if ((int)threadIdx.x < K) {
-    double f = 0.0;   // all-ones mask rows, summed by the rho pass (zero when the mask kernel handled them)
-    for (int sl = 0; sl < NSLOT; ++sl) f += slotF[((size_t)l * NSLOT + sl) * K + threadIdx.x];
-    fk[threadIdx.x] = f;
-    ela_old[threadIdx.x] = par[o.p_shp + l * K + threadIdx.x] / par[o.p_rte + l * K + threadIdx.x];
-    gla_old[threadIdx.x] = par[o.G_la + l * K + threadIdx.x];
+  const int l = blockIdx.x, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
+  if (tid < K) {
+    double fv[NSLOT], f = 0.0;   // all-ones mask rows, summed by the rho pass (zero when the mask kernel handled them)
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) fv[sl] = slotF[((size_t)l * NSLOT + sl) * K + tid];   // loads first, all in flight
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      f += fv[sl];
+      if (consume) slotF[((size_t)l * NSLOT + sl) * K + tid] = 0.0;
+    }
+    fk[tid] = f;
+    ela_old[tid] = par[o.p_shp + l * K + tid] / par[o.p_rte + l * K + tid];
+    gla_old[tid] = par[o.G_la + l * K + tid];
   }
+  for (int m = tid; m < g.Mp; m += FIN_TPB) s1[m] = 0.0;
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
   const size_t hcs = (size_t)g.Y * g.Mp * K;
-  const double* Hl = Hg + (size_t)l * NH * hcs;
-  double pr[KMAX], p0[KMAX];
-  for (int k = 0; k < KMAX; ++k) { pr[k] = 0.0; p0[k] = 0.0; }
-  for (int m = threadIdx.x; m < g.M; m += TPB) {
-    const size_t q = (size_t)l * g.Mp + m;
-    const double gth = par[o.G_th + q];   // still the old value
-    double s1 = 0.0;
-    for (int y = 0; y < g.Y; ++y)
-      for (int k = 0; k < K; ++k) {
-        const double h = h_at(Hl, hcs, ((size_t)y * g.Mp + m) * K + k);
-        s1 += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * h;
-        if (y == 0) p0[k] += h;
-      }
-    double A[KMAX], rte = 0.0;
+  double* Hl = Hg + (size_t)l * NH * hcs;
+  const int items = g.Y * g.Mp;
+  const bool phi2 = do_phi && g.mut;   // a second pass over H follows (phi_shp with the new E[log theta])
+  double p0[KMAX];
+  for (int k = 0; k < KMAX; ++k) p0[k] = 0.0;
+  for (int it = tid; it < items; it += FIN_TPB) {
+    const int y = it / g.Mp, m = it - y * g.Mp;
+    if (m >= g.M) continue;
+    const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // still the old value
+    double acc = 0.0;
     for (int k = 0; k < K; ++k) {
-      double ak = 0.0;
+      const size_t idx = (size_t)it * K + k;
+      const double hv = (consume && !phi2) ? h_sum<true>(Hl, hcs, idx) : h_sum<false>(Hl, hcs, idx);
+      acc += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * hv;
+      if (y == 0) p0[k] += hv;
+    }
+    if (acc != 0.0) atomicAdd(&s1[m], acc);
+  }
+  __syncthreads();
+  double pr[KMAX];
+  for (int k = 0; k < KMAX; ++k) pr[k] = 0.0;
+  for (int m = tid; m < g.M; m += FIN_TPB) {
+    const size_t q = (size_t)l * g.Mp + m;
+    double A[KMAX], rte = 0.0;
+    const double pa_th = par[o.a_th + q], pb_th = par[o.b_th + q];
+    for (int k = 0; k < K; ++k) {
+      double av[NSLOT], ak = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) av[sl] = slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];   // loads first
+#pragma unroll
       for (int sl = 0; sl < NSLOT; ++sl) {
-        double* pa = &slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];
-        ak += *pa; *pa = 0.0;   // consume: the slots are zero again for the next sweep
+        ak += av[sl];
+        slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k] = 0.0;   // consume: the slots are zero again for the next sweep
       }
       ak += fk[k];
       A[k] = ak;
       rte += ela_old[k] * ak;
     }
-    double shp = par[o.a_th + q] + s1;
-    rte = par[o.b_th + q] + rte;
+    double shp = pa_th + s1[m];
+    rte = pb_th + rte;
     par[o.g_shp + q] = shp; par[o.g_rte + q] = rte;
     double e = shp / rte, lg = digamma_pos(shp) - log(rte);
-    par[o.E_th + q] = e; par[o.l_th + q] = lg; par[o.G_th + q] = exp(lg);
+    const double gn = exp(lg);
+    par[o.E_th + q] = e; par[o.l_th + q] = lg; par[o.G_th + q] = gn;
+    gthn[m] = gn;
     for (int k = 0; k < K; ++k) pr[k] += e * A[k];
   }
   for (int k = 0; k < K; ++k) {
-    double v = block_sum(pr[k], red);
-    double ps = g.mut ? 0.0 : block_sum(p0[k], red);   // mutuality off: phi_shp = alpha + sum x rho_k (model.py:861-887)
-    if (threadIdx.x == 0) {
+    double v = block_sum_fin(pr[k], red);
+    double ps = g.mut ? 0.0 : block_sum_fin(p0[k], red);   // mutuality off: phi_shp = alpha + sum x rho_k (model.py:861-887)
+    if (tid == 0) {
       double rte = par[o.b_la + l * K + k] + v;
       if (g.mut) {
         par[o.p_rte_pend + l * K + k] = rte;
@@ -1703,18 +1775,22 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
   // (fused sweep) phi right away: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887),
   // phi_rte as just computed; then the nibble LUT of the new E[theta] for the rho pass
   __syncthreads();
-  if (do_phi && g.mut) {
-    const double gnu2 = par[o.sc + SC_G_NU];
+  if (phi2) {
     double ps[KMAX];
     for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
-    for (int m = threadIdx.x; m < g.M; m += TPB) {
-      const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // new (written above by this workgroup)
-      for (int y = 0; y < g.Y; ++y)
-        for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu2 * (double)y) * h_at(Hl, hcs, ((size_t)y * g.Mp + m) * K + k);
+    for (int it = tid; it < items; it += FIN_TPB) {
+      const int y = it / g.Mp, m = it - y * g.Mp;
+      if (m >= g.M) continue;
+      const double gth = gthn[m];
+      for (int k = 0; k < K; ++k) {
+        const size_t idx = (size_t)it * K + k;
+        const double hv = consume ? h_sum<true>(Hl, hcs, idx) : h_sum<false>(Hl, hcs, idx);
+        ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * hv;
+      }
     }
     for (int k = 0; k < K; ++k) {
-      double v = block_sum(ps[k], red);
-      if (threadIdx.x == 0) {
+      double v = block_sum_fin(ps[k], red);
+      if (tid == 0) {
         const int q = l * K + k;
         double shp = par[o.a_la + q] + v, rte = par[o.p_rte_pend + q];
         par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
@@ -1724,7 +1800,7 @@ __global__ __launch_bounds__(TPB) void k_fin_gamma(double* par, const double* __
     }
   }
   const double* Eth = par + o.E_th + (size_t)l * g.Mp;
-  for (int q = threadIdx.x; q < g.W * 256; q += TPB) {
+  for (int q = tid; q < g.W * 256; q += FIN_TPB) {
     int n = q >> 4, e = q & 15;
     double v = 0.0;
     for (int u = 0; u < 4; ++u) {
@@ -1774,37 +1850,42 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 // nu from H of the new rho (model.py:694-696, 822-825: sum x w2_k rho_k) and/or ELBO assembly (model.py:997-1013).
 // One workgroup per layer adds its share to fin[0..1] with device-scope atomics; the workgroup that draws the
 // last ticket (fin[2]) finishes the scalars and clears the scratch.
-__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, const double* __restrict__ Hg, double* slotR, double* elbo_out,
-                                                 double* fin, int do_nu, int do_elbo, Geo g) {
+#define FR_G 16   // workgroups per layer of k_fin_rho
+__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, double* slotR, double* elbo_out,
+                                                 double* fin, int do_nu, int do_elbo, int fold, Geo g) {
   __shared__ double red[8];
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
-  const int l = blockIdx.x;
+  const int l = blockIdx.x / FR_G, gs = blockIdx.x - l * FR_G;
   double a0 = 0.0, gt = 0.0;
-  if (g.mut) {
+  if (g.mut || fold) {   // threads take (y, m) items of H; fold: the NH copies are summed into copy 0 on the way
     const double gnu = sc[SC_G_NU];
     const size_t hcs = (size_t)g.Y * g.Mp * g.K;
-    const double* Hl = Hg + (size_t)l * NH * hcs;
-    for (int m = threadIdx.x; m < g.M; m += TPB) {
-      const double gth = par[o.G_th + (size_t)l * g.Mp + m];
+    double* Hl = Hg + (size_t)l * NH * hcs;
+    const int items = g.Y * g.Mp, i0 = (int)((long long)gs * items / FR_G), i1 = (int)((long long)(gs + 1) * items / FR_G);
+    for (int it = i0 + (int)threadIdx.x; it < i1; it += TPB) {
+      const int y = it / g.Mp, m = it - y * g.Mp;
+      if (m >= g.M || (y == 0 && !fold)) continue;
+      const double gth = par[o.G_th + (size_t)l * g.Mp + m], z2 = gnu * (double)y;
       for (int k = 0; k < g.K; ++k) {
+        const size_t idx = (size_t)it * g.K + k;
+        const double hv = fold ? h_fold(Hl, hcs, idx) : Hl[idx];
         const double z1 = gth * par[o.G_la + l * g.K + k];
-        for (int y = 1; y < g.Y; ++y) {
-          const double z2 = gnu * (double)y;
-          a0 += (z2 / (z1 + z2)) * h_at(Hl, hcs, ((size_t)y * g.Mp + m) * g.K + k);
-        }
+        if (g.mut && y > 0) a0 += (z2 / (z1 + z2)) * hv;
       }
     }
   }
   if (do_elbo) {
-    for (int m = threadIdx.x; m < g.M; m += TPB) {
+    for (int m = gs * TPB + threadIdx.x; m < g.M; m += FR_G * TPB) {
       const size_t q = (size_t)l * g.Mp + m;
       gt += gamma_elbo_term(par[o.a_th + q], par[o.b_th + q], par[o.g_shp + q], par[o.g_rte + q]);
     }
-    for (int k = threadIdx.x; k < g.K; k += TPB) {
-      const int q = l * g.K + k;
-      gt += gamma_elbo_term(par[o.a_la + q], par[o.b_la + q], par[o.p_shp + q], par[o.p_rte + q]);
+    if (gs == 0) {
+      for (int k = threadIdx.x; k < g.K; k += TPB) {
+        const int q = l * g.K + k;
+        gt += gamma_elbo_term(par[o.a_la + q], par[o.b_la + q], par[o.p_shp + q], par[o.p_rte + q]);
+      }
     }
   }
   a0 = block_sum(a0, red);
@@ -1944,6 +2025,30 @@ static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl, long long ca
   return VMR_OK;
 }
 
+// k_fin_rho: nu and/or the ELBO; folds the NH copies of H into copy 0 on its way when they are not folded yet
+static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo) {
+  const Geo& g = h->g;
+  const int fold = (h->h_valid && !h->h_reduced) ? 1 : 0;
+  {
+    Prof p(h, VMR_KERNEL_FINALIZE);
+    hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev,
+                       h->elbo_dev + 4, do_nu, do_elbo, fold, g);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (fold) h->h_reduced = true;
+  return VMR_OK;
+}
+// before k_fin_gamma / k_fin_phi read H outside the fused sweep
+static int ensure_h_folded(vmr_ctx* h) {
+  if (h->h_reduced) return VMR_OK;
+  const Geo& g = h->g;
+  const size_t n = (size_t)g.L * g.Y * g.Mp * g.K;
+  hipLaunchKernelGGL(k_h_reduce, dim3((unsigned)std::min<size_t>(1024, (n + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, g);
+  HIPCHK(h, hipGetLastError());
+  h->h_reduced = true;
+  return VMR_OK;
+}
+
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
 static int launch_hist(vmr_ctx* h) {
   const Geo& g = h->g;
@@ -1972,6 +2077,8 @@ static int launch_hist(vmr_ctx* h) {
   }
   HIPCHK(h, hipGetLastError());
   h->h_valid = true;
+  h->h_zero = false;
+  h->h_reduced = false;
   return VMR_OK;
 }
 
@@ -2005,9 +2112,19 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     int rc = launch_hist(h);
     if (rc) return rc;
   }
+  { int rc = ensure_h_folded(h); if (rc) return rc; }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg, with_phi ? 1 : 0, g);
+    // fused sweep: this is the last reader of H and slotF before the rho pass rebuilds them, so it leaves them zeroed
+    const int consume = (with_phi && !g.two_pass) ? 1 : 0;
+    const size_t fsm = (size_t)2 * g.Mp * 8;
+    if (fsm > 48 * 1024 && !h->fin_attr) {
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fin_gamma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm));
+      h->fin_attr = true;
+    }
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg,
+                       with_phi ? 1 : 0, consume, g);
+    if (consume) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
   }
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
@@ -2017,6 +2134,7 @@ static int launch_phi(vmr_ctx* h) {
   const Geo& g = h->g;
   if (!g.mut) return VMR_OK;   // committed by k_fin_gamma
   if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
+  { int rc = ensure_h_folded(h); if (rc) return rc; }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_phi, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, g);
@@ -2032,8 +2150,11 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
   int rc = VMR_OK;
-  if (mode != 2 && g.fuse_full) HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
-  if (mode != 2 && !g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
+  if (mode != 2 && !h->h_zero) {   // (after a fused k_fin_gamma both are zero already)
+    if (g.fuse_full) HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
+    if (!g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
+  }
+  if (mode != 2) h->h_zero = false;
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     SpArgs s{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
@@ -2064,14 +2185,13 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (mode != 2) {
     h->f_valid = g.fuse_full != 0;
     h->h_valid = !g.two_pass;
+    if (!g.two_pass) h->h_reduced = false;
     if (g.two_pass && (rc = launch_hist(h))) return rc;   // wide reporter dimension: second pass rebuilds H
   }
-  if (mode != 0 || commit_nu) {
-    Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4,
-                       (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0, g);
-  }
   HIPCHK(h, hipGetLastError());
+  if (mode != 0 || commit_nu) {
+    if ((rc = launch_fin_rho(h, (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0))) return rc;
+  }
   return VMR_OK;
 }
 
@@ -2437,9 +2557,7 @@ int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   if ((rc = launch_gamma(h, true))) return rc;
   if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;   // rho updated, nu NOT committed
   if (!want_elbo) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
-    Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(h->g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4, 0, 0, h->g);
-    HIPCHK(h, hipGetLastError());
+    if ((rc = launch_fin_rho(h, 0, 0))) return rc;
   }
   double v[4];
   HIPCHK(h, hipMemcpyAsync(v, h->elbo_dev, 32, hipMemcpyDeviceToHost, h->stream));
@@ -2468,11 +2586,8 @@ int vmr_sub_step(vmr_handle h, int which) {
     case VMR_STEP_RHO: return launch_rho(h, 0, false);
     case VMR_STEP_NU: {
       if (!h->g.mut) return VMR_OK;
-      Prof p(h, VMR_KERNEL_FINALIZE);
       if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
-      hipLaunchKernelGGL(k_fin_rho, dim3(h->g.L), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev, h->elbo_dev + 4, 1, 0, h->g);
-      HIPCHK(h, hipGetLastError());
-      return VMR_OK;
+      return launch_fin_rho(h, 1, 0);
     }
     default: return fail(h, VMR_EINVAL, "unknown sub-step");
   }
