@@ -8,7 +8,14 @@
 
 A "step" is one full CAVI sweep (gamma, phi, rho, nu: reference model.py:623-660) with the ELBO
 evaluated at the reference cadence (iteration 1 and every 10th, model.py:1036).  Inputs are
-resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+resident in HBM before the timed region (vmr_create has already turned the dense count tensor into
+report lists: 4 B per non-zero count).  Prints ONE JSON line (rank 0).
+
+roofline: the dominant kernel's ALGORITHMIC bytes under the data format in use (vmr_kernel_bytes: report
+lists = 4 B per non-zero count + 4 B per tie + log-prior read + rho write) over its average
+launch time from HIP events on the engine's stream; `traffic` = HBM bytes per launch from rocprofv3
+FETCH_SIZE x2 + WRITE_SIZE (profiles/, tools/profile_gpu.sh).  `sweep` restates the whole sweep against
+SURVEY 8(d)'s canonical DENSE byte model (12.2 GB per iteration), which this format no longer moves.
 """
 import argparse
 import json
@@ -88,6 +95,7 @@ def main():
     t_gen = time.time() - t_gen
     eng = CaviEngine(net.X, R, K=K, mutuality=cfg["mutuality"], device=local)
     sum_x, cov = eng.data_stats()
+    fmt, _ = eng.data_format()
     seed = 1 + rank
     host, pr = draw_state(cfg, seed, sum_x, cov)
     eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
@@ -159,17 +167,21 @@ def main():
                                    f"eta={cfg['eta']}, R dense all-ones, one seed-fit per GPU" if args.config == "c3"
                                    else args.config,
                        "L": L, "N": N, "M": M, "K": K, "mutuality": cfg["mutuality"], "nnz_X": nnz,
+                       "data_format": "report lists (4 B per non-zero count)" if fmt == "sparse" else "dense u8 tiles",
                        "elbo_cadence": "iter 1 and every 10th (fused into the rho pass)", "parallelism": f"fits x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": d["bytes_per_launch"]},
+                         "algorithmic_bytes_per_launch": d["bytes_per_launch"],
+                         "byte_model": ("report lists: 4 B x nnz(X) + 4 B x ties + log-prior read + rho write"
+                                        if fmt == "sparse" else "dense: X 1 B/elt + R 1 bit/elt + log-prior read + rho write")},
             "kernels": {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches": v["launches"],
                             "GBps": (v["bytes_per_launch"] / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9)
                             if v["ms"] > 0 and v["bytes_per_launch"] > 0 else None} for k, v in prof.items()},
             "elbo": elbos, "gen_seconds": t_gen,
         }
-        # whole-sweep view: SURVEY 8(d)'s canonical bytes per iteration (three passes over X,R + ELBO share) against
-        # the wall time of a sweep -- the engine needs ONE pass over X per sweep (sufficient statistics)
+        # whole-sweep view: SURVEY 8(d)'s canonical DENSE bytes per iteration (three passes over X,R + ELBO share)
+        # against the wall time of a sweep.  The engine makes ONE pass per sweep (sufficient statistics) over report
+        # lists, so this "equivalent" rate may exceed the HBM peak: it is a statement about bytes avoided.
         V = float(L) * N * N * M
         srho = 8.0 * L * N * N * K
         b_iter = 3.0 * (V + V / 8.0) + 4.0 * srho

@@ -78,7 +78,7 @@ def main():
                 elif "k_rho" in name:
                     flags = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
                     upd, elbo = flags[2] == "true", flags[3] == "true"
-                    cls = "rho_elbo" if (upd and elbo) else ("rho" if upd else "elbo")
+                    cls = "rho_elbo" if (upd and elbo) else ("rho" if upd else ("elbo" if elbo else "gamma_counts"))
                 if cls:
                     traffic[cls] = rd + wb
         pj = os.path.join(dst, "pmc_traffic.json")
