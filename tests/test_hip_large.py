@@ -100,6 +100,45 @@ def test_k5_categories():
     _run(L=1, N=150, M=64, K=5, eta=0.5, mutuality=True, mask="mixed", sweeps=3)
 
 
+def test_m1000_k3_mutuality_two_lds_levels():
+    _run(L=1, N=60, M=1000, K=3, eta=0.5, mutuality=True, mask="ones", sweeps=2)       # H levels 0-1 in LDS beside the rho pass
+
+
+def test_m1500_k4_statistics_in_a_second_pass():
+    _run(L=1, N=40, M=1500, K=4, eta=0.5, mutuality=True, mask="random", sweeps=2)     # tables too wide: two passes per sweep
+
+
+def test_dense_and_report_list_formats_agree(monkeypatch):
+    """The two data layouts of the engine (vmr_data_format) are two implementations of the same sweep."""
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    L, N, M, K = 2, 96, 120, 2
+    net = standard_sbm(N=N, M=M, L=L, K=K, avg_degree=5.0, eta=0.5, seed=3)
+    g = np.random.RandomState(5)
+    kind = g.randint(0, 3, size=(L, N, N, 1))
+    R = np.where(kind == 0, 1, np.where(kind == 1, 0, g.rand(L, N, N, M) < 0.5)).astype(np.uint8)
+    pr = 1.0 + 0.01 * g.rand(L, N, N, K)
+    pr /= pr.sum(-1)[..., None]
+    init = (0.1 + 0.1 * g.rand(L, M), 0.1 + 0.1 * g.rand(L, M), 10 + 10 * g.rand(L, K), 10 + 10 * g.rand(L, K), 0.7,
+            1.0 + float(net.X.sum()), pr)
+    out = {}
+    for fmt in ("dense", "sparse"):
+        monkeypatch.setenv("VMR_FORMAT", fmt)
+        eng = CaviEngine(net.X, R, K=K, mutuality=True)
+        assert eng.data_format() == (fmt, int((net.X != 0).sum()) if fmt == "sparse" else eng.data_format()[1])
+        eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+        eng.set_state(*init)
+        e = [eng.step(1, want_elbo=True) for _ in range(4)]
+        out[fmt] = (e, eng.elbo(), eng.get_state())
+        eng.close()
+    (ed, ed2, sd), (es, es2, ss) = out["dense"], out["sparse"]
+    np.testing.assert_allclose(es, ed, rtol=1e-11)
+    assert abs(es2 - ed2) <= 1e-11 * abs(ed2)
+    for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):
+        np.testing.assert_allclose(ss[k], sd[k], rtol=1e-11)
+    np.testing.assert_allclose(ss["rho"], sd["rho"], rtol=1e-9, atol=1e-13)
+
+
 def test_m50_small_rows():
     _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones")
 

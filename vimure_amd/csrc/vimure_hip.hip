@@ -2387,9 +2387,19 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
     g.two_pass = 0;
     size_t need = 0;
     if (h->sparse) {
-      if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
-        g.two_pass = 1;
-        while (g.hc > 0 && shmem_sp(g, false, false, true) > 160000) --g.hc;
+      if (const char* fh = getenv("VMR_HC")) {   // experiment: force the number of LDS levels (one pass if it fits)
+        g.hc = std::max(0, std::min(atoi(fh), g.hc));
+        g.two_pass = shmem_sp(g, g.mut != 0, true, true) > 160000 ? 1 : 0;
+      } else if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
+        // wide reporter dimension.  Two levels beside the rho pass' tables (2 workgroups per CU) beat a second pass
+        // with three (M = 1000, K = 3, N = 3000: 3.0 vs 3.8 ms per sweep; ONE level: 14 ms, level 1 is populous)
+        const int hc3 = g.hc;
+        g.hc = std::min(g.hc, 2);
+        if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
+          g.hc = hc3;
+          g.two_pass = 1;
+          while (g.hc > 0 && shmem_sp(g, false, false, true) > 160000) --g.hc;
+        }
       }
       need = std::max(shmem_sp(g, g.mut != 0, true, !g.two_pass), shmem_sp(g, false, false, true));
     } else {
