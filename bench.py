@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (bounded sample)")
+    ap.add_argument("--format", default="auto", choices=["auto", "dense", "sparse"],
+                    help="engine data layout (VMR_FORMAT): report lists unless X is dense; 'dense' forces the tile path")
+    ap.add_argument("--no-converge", action="store_true", help="skip the time-to-ELBO-converge fit")
     args = ap.parse_args()
 
     import torch
@@ -84,6 +87,8 @@ def main():
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
 
+    if args.format != "auto":
+        os.environ["VMR_FORMAT"] = args.format
     cfg = CONFIGS[args.config]
     L, N, M, K = cfg["L"], cfg["N"], cfg["M"], cfg["K"]
     t_gen = time.time()
@@ -154,7 +159,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get(dom)
+                traffic = json.load(open(pmc)).get(args.config + ("" if fmt == "sparse" else "_dense"), {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -189,12 +194,31 @@ def main():
         out["sweep"] = {"canonical_bytes_per_iter": b_iter + b_elbo / 10.0,
                         "canonical_equiv_GBps": (b_iter + b_elbo / 10.0) / (dt / args.steps) / 1e9,
                         "iter_per_s_at_8TBps_canonical": HBM_PEAK_GBS * 1e9 / (b_iter + b_elbo / 10.0)}
+        if not args.no_converge:
+            out["time_to_converge"] = time_to_converge(cfg, net, eng, seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds, eng)
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def time_to_converge(cfg, net, eng, seed):
+    """BASELINE's second figure: one realisation of VimureModel.fit on the resident dataset until the reference's
+    stop rule fires (|dELBO| < 0.1 on two consecutive checks, checks at iteration 1 and every 10th; model.py:1036-1056).
+    Outside the timed region of `value`."""
+    import warnings
+    from vimure_amd import VimureModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel(mutuality=cfg["mutuality"])
+        t0 = time.perf_counter()
+        m.fit(net.X, K=cfg["K"], seed=seed, engine=eng, num_realisations=1, max_iter=2000)
+        wall = time.perf_counter() - t0
+    return {"iterations": int(m.trace["iter"].max()), "converged": bool(m.trace["reached_convergence"].iloc[-1]),
+            "loop_seconds": m.loop_seconds, "fit_seconds": wall, "elbo": float(m.maxL),
+            "note": "fit_seconds adds the host-side RandomState draw of pr_rho, its upload and the read-back of rho"}
 
 
 def cpu_baseline(cfg, net, R, host, pr, budget_s, eng):

@@ -230,6 +230,7 @@ class VimureModel(TransformerMixin, BaseEstimator):
             eng.set_priors(self.alpha_theta, self.beta_theta, self.alpha_lambda, self.beta_lambda,
                            self.alpha_mutuality, self.beta_mutuality)
             maxL, trace = -INF, []
+            self.loop_seconds = 0.0   # wall time inside the CAVI loops of all realisations (device work included)
             for r in range(self.num_realisations):
                 bias = DEFAULT_BIAS0 if r < 5 else (r - 4) * self.bias0
                 pr_rho = self._draw_pr_rho(coverage, bias)
@@ -238,6 +239,7 @@ class VimureModel(TransformerMixin, BaseEstimator):
                               pr_rho)
                 del pr_rho
                 coincide, it, reached, elbo = 0, 1, False, -INF
+                t_loop = time.perf_counter()
                 while not reached and it <= self.max_iter:
                     check = it == 1 or it % 10 == 0 or it == self.max_iter
                     t0 = time.time()
@@ -255,6 +257,8 @@ class VimureModel(TransformerMixin, BaseEstimator):
                     it += 1
                     if (it - 1) % 10 == 0:
                         trace.append((r, self.seed, it - 1, elbo, runtime, reached))
+                eng.sync()
+                self.loop_seconds += time.perf_counter() - t_loop
                 self._pull_state(eng)
                 if maxL < elbo:
                     self._update_optimal_parameters()
