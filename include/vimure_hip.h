@@ -148,6 +148,11 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes);
  * (0 when the dense format was forced before counting).  Either pointer may be NULL. */
 int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz);
 
+/* Mask layout: *lists = 1 when the partial rows of R are also held as short reporter lists (rows with few
+ * reporters, e.g. the self-reporter mask of _io.py:230-242; env VMR_NO_RLISTS=1 disables), *listed = reporters in
+ * those lists.  The bit-packed mask is kept either way.  Either pointer may be NULL. */
+int vmr_mask_format(vmr_handle h, int* lists, uint64_t* listed);
+
 /* Library/version string. */
 const char* vmr_version(void);
 

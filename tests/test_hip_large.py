@@ -139,6 +139,42 @@ def test_dense_and_report_list_formats_agree(monkeypatch):
     np.testing.assert_allclose(ss["rho"], sd["rho"], rtol=1e-9, atol=1e-13)
 
 
+def test_self_reporter_mask_lists_agree_with_mask_words(monkeypatch):
+    """Karnataka-shaped mask (R = 1 iff the reporter is one end of the tie): partial rows are walked as reporter
+    lists; the same fit with the lists disabled reads the bit-packed words."""
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    L, N, K = 2, 280, 2   # 5 mask words per row against a 2-reporter list
+    net = standard_sbm(N=N, M=N, L=L, K=K, avg_degree=3.0, eta=0.3, seed=4, flag_self_reporter=True)
+    g = np.random.RandomState(6)
+    pr = 1.0 + 0.01 * g.rand(L, N, N, K)
+    pr /= pr.sum(-1)[..., None]
+    init = (0.1 + 0.1 * g.rand(L, N), 0.1 + 0.1 * g.rand(L, N), 10 + 10 * g.rand(L, K), 10 + 10 * g.rand(L, K), 0.7,
+            1.0 + float(net.X.sum()), pr)
+    c = cavi_ref.CRef(net.X, net.R, K, True, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), init[0], init[1], init[2], init[3],
+                      init[4], init[5], pr)
+    for _ in range(4):
+        c.cavi_step()
+    e_cpu = c.elbo()
+    out = {}
+    for mode in ("lists", "words"):
+        if mode == "words":
+            monkeypatch.setenv("VMR_NO_RLISTS", "1")
+        eng = CaviEngine(net.X, net.R, K=K, mutuality=True)
+        assert eng.mask_format() == (mode, int(net.R.sum()) if mode == "lists" else 0)
+        eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+        eng.set_state(*init)
+        e = eng.step(4, want_elbo=True)
+        st = eng.get_state()
+        assert abs(e - e_cpu) <= 1e-9 * abs(e_cpu)
+        np.testing.assert_allclose(st["gamma_rte"], c.gamma_rte, rtol=1e-9)
+        np.testing.assert_allclose(st["phi_rte"], c.phi_rte, rtol=1e-9)
+        np.testing.assert_allclose(st["rho"], c.rho, rtol=1e-7, atol=1e-12)
+        out[mode] = (e, st)
+        eng.close()
+    assert abs(out["lists"][0] - out["words"][0]) <= 1e-11 * abs(e_cpu)
+
+
 def test_m50_small_rows():
     _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones")
 

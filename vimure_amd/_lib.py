@@ -38,6 +38,7 @@ SIGNATURES = {
     "vmr_profile_read": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "vmr_kernel_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_data_format": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "vmr_mask_format": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "vmr_version": (C.c_char_p, []),
 }
 

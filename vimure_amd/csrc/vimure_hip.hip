@@ -91,6 +91,11 @@ struct vmr_ctx {
   unsigned long long* ebase = nullptr;   // device [L]
   unsigned long long nnz = 0;  // non-zero counts in X
   int all_full = 0;            // every mask row is all ones
+  // mask lists (partial rows with few reporters), see k_mask_lists
+  unsigned* rq = nullptr;              // [L][N*N+1]
+  unsigned short* Rm = nullptr;
+  unsigned long long* rbase = nullptr; // device [L]
+  unsigned long long n_rm = 0;         // listed reporters in all
   unsigned long long* sumx = nullptr;
   // state
   double *rho = nullptr, *logpr = nullptr;
@@ -104,7 +109,7 @@ struct vmr_ctx {
   bool f_valid = false;        // slotF matches the current rho
   bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
   bool h_zero = false;         // k_fin_gamma consumed H and slotF: both are all zero, ready for the rho pass
-  bool fin_attr = false;
+  bool fin_attr = false, ml_attr = false;
   unsigned long long* npartial = nullptr;   // rows of R that are neither empty nor all ones
   unsigned long long n_partial = 0;
   unsigned* xmax = nullptr;
@@ -1294,10 +1299,87 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Mask lists: a partial mask row as the list of its reporters (u16), for masks whose partial rows hold few
+// reporters (the self-reporter mask of survey data: R[l,i,j,m] = 1 iff m is i or j, two per row).  Reading 4 bytes
+// per row instead of W words makes the mask sums A and the per-tie T of such data a few microseconds.
+// rq[l][t] (u32, N*N+1 per layer): first reporter of tie t's list, relative to rbase[l]; empty for rows that are
+// not partial.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rm_count(const uint64_t* __restrict__ Rl, const uint8_t* __restrict__ cl,
+                                                  unsigned* __restrict__ rql, unsigned long long* total, unsigned* maxrow,
+                                                  size_t T, int W) {
+  __shared__ double red[8];
+  unsigned long long mine = 0;
+  unsigned mx = 0;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (size_t)gridDim.x * 256) {
+    unsigned n = 0;
+    if (cl[t] == 2) for (int w = 0; w < W; ++w) n += (unsigned)__popcll(Rl[t * W + w]);
+    rql[t] = n;
+    mine += n;
+    mx = max(mx, n);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) rql[T] = 0u;
+  double v = block_sum((double)mine, red);
+  if (threadIdx.x == 0 && v > 0.0) atomicAdd(total, (unsigned long long)v);
+  if (mx) atomicMax(maxrow, mx);
+}
+__global__ __launch_bounds__(256) void k_rm_fill(const uint64_t* __restrict__ Rl, const uint8_t* __restrict__ cl,
+                                                 const unsigned* __restrict__ rql, unsigned short* __restrict__ Rml, size_t T, int W) {
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (size_t)gridDim.x * 256) {
+    if (cl[t] != 2) continue;
+    size_t q = rql[t];
+    for (int w = 0; w < W; ++w) {
+      uint64_t bits = Rl[t * W + w];
+      while (bits) {
+        const int b_ = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        Rml[q++] = (unsigned short)(w * 64 + b_);
+      }
+    }
+  }
+}
+// A[l,m,k] += rho[l,t,k] over the listed reporters of the partial rows (model.py:704-718, 742-749); all-ones rows
+// were summed by the rho pass.  One thread per tie, A of the workgroup in LDS, one global add per value at the end.
+template <int K>
+__global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__ rq, const unsigned short* __restrict__ Rm,
+                                                    const unsigned long long* __restrict__ rbase, const uint8_t* __restrict__ rcls,
+                                                    const double* __restrict__ rho, double* __restrict__ slotA, int Gl, Geo g) {
+  extern __shared__ double As[];   // [Mp][K]
+  const int l = blockIdx.x / Gl, gb = blockIdx.x - l * Gl;
+  const size_t T = (size_t)g.N * g.N;
+  const unsigned* rql = rq + (size_t)l * (T + 1);
+  const unsigned short* Rml = Rm + rbase[l];
+  const uint8_t* cl = rcls + (size_t)l * T;
+  const double* rl = rho + (size_t)l * T * K;
+  for (int q = threadIdx.x; q < g.Mp * K; q += TPB) As[q] = 0.0;
+  __syncthreads();
+  const size_t t0 = (size_t)gb * T / Gl, t1 = (size_t)(gb + 1) * T / Gl;
+  for (size_t t = t0 + threadIdx.x; t < t1; t += TPB) {
+    if (cl[t] != 2) continue;
+    const unsigned q0 = rql[t], q1 = rql[t + 1];
+    double r[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = rl[t * K + k];
+    for (unsigned q = q0; q < q1; ++q) {
+      const int m = Rml[q];
+#pragma unroll
+      for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], r[k]);
+    }
+  }
+  __syncthreads();
+  double* out = slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
+  for (int q = threadIdx.x; q < g.M * K; q += TPB) {
+    const double v = As[q];
+    if (v != 0.0) atomicAdd(&out[q], v);
+  }
+}
+
 struct SpArgs {
   const unsigned* E; const unsigned* rp; const unsigned long long* ebase; const uint64_t* Rb; const uint8_t* rcls;
   double* rho; const double* logpr; const double* par; double* slotR; const double* lutg; double* Hg; double* slotF;
   const unsigned* Qt;
+  const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask lists (null: read the mask words)
   int Gl, all_full, do_hist;
 };
 
@@ -1377,6 +1459,9 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   const unsigned* Ql = a.Qt + (size_t)l * T;
   double* rl = a.rho + (size_t)l * T * K;
   const double* lpl = a.logpr + (size_t)l * T * K;
+  const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
+  const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
+  const double* Eth = a.par + o.E_th + (size_t)l * g.Mp;
 
   // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 entries of
   // the wave's next step and the entry range of the one after are in flight.
@@ -1460,7 +1545,10 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
     bool rowfull = false;
     if (UPDATE || ELBO) {   // T = sum_m R E[theta_m] (model.py:766-792)
       if (cls == 1u) { Tt = Tfull; rowfull = true; }
-      else if (cls == 2u) {
+      else if (cls == 2u && a.rq) {   // a short list of reporters
+        const unsigned q0 = rql[t], q1 = rql[t + 1];
+        for (unsigned q = q0; q < q1; ++q) Tt += Eth[Rml[q]];
+      } else if (cls == 2u) {
         const uint64_t* rwt = Rl + t * g.W;
         for (int w = 0; w < g.W; ++w) {
           uint64_t bits = rwt[w];
@@ -2056,7 +2144,7 @@ static int launch_hist(vmr_ctx* h) {
   if (h->sparse) {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     SpArgs a{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-             1, h->all_full, 1};
+             h->rq, h->Rm, h->rbase, 1, h->all_full, 1};
     const size_t sm = shmem_sp(g, false, false, true);
     const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;   // at least one 64-tie step per wave
     int rc = VMR_OK;
@@ -2093,7 +2181,19 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
   // mask rows that are all ones were already summed by the last rho pass (slotF); the mask kernel then only
   // handles partial rows, and is not needed at all when R has none
   const int skip_full = (g.fuse_full && h->f_valid) ? 1 : 0;
-  if (!skip_full || h->n_partial > 0) {
+  if (skip_full && h->n_partial > 0 && h->rq) {   // partial rows only, and they are short lists
+    Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
+    const size_t T_ = (size_t)g.N * g.N;
+    int gl = (int)std::min<size_t>(std::max<size_t>(1, (size_t)h->ncu / g.L), (T_ + 4 * TPB - 1) / (4 * TPB));
+    const size_t lsm = (size_t)g.Mp * g.K * 8;
+    if (lsm > 48 * 1024 && !h->ml_attr) {
+      DISPATCH_K(g.K, HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mask_lists<KK>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsm)));
+      h->ml_attr = true;
+    }
+    DISPATCH_K(g.K, hipLaunchKernelGGL((k_mask_lists<KK>), dim3(g.L * gl), dim3(TPB), lsm, ms, h->rq, h->Rm, h->rbase,
+                                       h->rcls, h->rho, h->slotA, gl, g));
+  } else if (!skip_full || h->n_partial > 0) {
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
     switch (g.W >= 4 ? 4 : g.W) {
@@ -2158,7 +2258,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     SpArgs s{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-             1, h->all_full, (mode != 2 && !g.two_pass) ? 1 : 0};
+             h->rq, h->Rm, h->rbase, 1, h->all_full, (mode != 2 && !g.two_pass) ? 1 : 0};
     const size_t ssm = shmem_sp(g, g.mut != 0, mode != 0, s.do_hist != 0);
     const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
 #define LSP(MUT_, UPD_, ELB_)                                                                  \
@@ -2369,6 +2469,54 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
           }
           CCHK(hipGetLastError());
           CCHK(hipStreamSynchronize(h->stream));
+          // ---- mask lists for partial rows that hold few reporters (self-reporter masks: two per row) ----
+          if (h->n_partial > 0 && !getenv("VMR_NO_RLISTS")) {
+            unsigned long long* tot_dev = nullptr;
+            unsigned* max_dev = nullptr;
+            CCHK(hipMalloc(&h->rq, (size_t)L * n * 4));
+            CCHK(hipMalloc(&tot_dev, (size_t)L * 8));
+            CCHK(hipMalloc(&max_dev, 4));
+            CCHK(hipMemsetAsync(tot_dev, 0, (size_t)L * 8, h->stream));
+            CCHK(hipMemsetAsync(max_dev, 0, 4, h->stream));
+            const unsigned rgrid = (unsigned)std::min<size_t>(4096, (T + 255) / 256);
+            for (int l = 0; l < L; ++l)
+              hipLaunchKernelGGL(k_rm_count, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
+                                 h->rcls + (size_t)l * T, h->rq + (size_t)l * n, tot_dev + l, max_dev, T, g.W);
+            CCHK(hipGetLastError());
+            CCHK(hipStreamSynchronize(h->stream));
+            std::vector<unsigned long long> rl_(L), rb_(L);
+            unsigned maxrow = 0;
+            CCHK(hipMemcpy(rl_.data(), tot_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
+            CCHK(hipMemcpy(&maxrow, max_dev, 4, hipMemcpyDeviceToHost));
+            CCHK(hipFree(tot_dev));
+            CCHK(hipFree(max_dev));
+            bool ok32 = true;
+            h->n_rm = 0;
+            for (int l = 0; l < L; ++l) { rb_[l] = h->n_rm; h->n_rm += rl_[l]; ok32 = ok32 && rl_[l] < 0xffffffffull; }
+            // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row)
+            const double list_bytes = 2.0 * (double)h->n_rm + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
+            if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes) {
+              for (int l = 0; l < L; ++l) {
+                unsigned* rql = h->rq + (size_t)l * n;
+                hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rql, bsum, n);
+                hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs);
+                hipLaunchKernelGGL(k_scan_add, dim3(nbs), dim3(256), 0, h->stream, rql, bsum, n);
+              }
+              CCHK(hipGetLastError());
+              CCHK(hipMalloc(&h->rbase, (size_t)L * 8));
+              CCHK(hipMemcpyAsync(h->rbase, rb_.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
+              CCHK(hipMalloc(&h->Rm, ((size_t)h->n_rm + 64) * 2));
+              for (int l = 0; l < L; ++l)
+                hipLaunchKernelGGL(k_rm_fill, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
+                                   h->rcls + (size_t)l * T, h->rq + (size_t)l * n, h->Rm + rb_[l], T, g.W);
+              CCHK(hipGetLastError());
+              CCHK(hipStreamSynchronize(h->stream));
+            } else {
+              CCHK(hipFree(h->rq));
+              h->rq = nullptr;
+              h->n_rm = 0;
+            }
+          }
           CCHK(hipFree(bsum));
           if (!getenv("VMR_KEEP_X")) { CCHK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
         } else {
@@ -2435,7 +2583,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->E, h->rp, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rp, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -2688,6 +2836,13 @@ int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz) {
   return VMR_OK;
 }
 
+int vmr_mask_format(vmr_handle h, int* lists, uint64_t* listed) {
+  if (!h) return VMR_EINVAL;
+  if (lists) *lists = h->rq ? 1 : 0;
+  if (listed) *listed = h->n_rm;
+  return VMR_OK;
+}
+
 int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   if (!h || !bytes) return VMR_EINVAL;
   const Geo& g = h->g;
@@ -2696,10 +2851,10 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
     const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties + g.L);
-    const double mask = h->all_full ? 0.0 : ties + (double)h->n_partial * g.W * 8.0;
+    const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {
-      case VMR_KERNEL_GAMMA_MASK: *bytes = ties + (double)h->n_partial * g.W * 8.0 + Srho; break;
+      case VMR_KERNEL_GAMMA_MASK: *bytes = ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0) + Srho; break;
       case VMR_KERNEL_GAMMA_COUNTS: *bytes = E + RP + Srho; break;
       case VMR_KERNEL_RHO: *bytes = E + RP + mask + 2.0 * Srho; break;
       case VMR_KERNEL_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;

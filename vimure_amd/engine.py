@@ -171,6 +171,12 @@ class CaviEngine:
         self._check(self.lib.vmr_data_format(self._h, C.byref(sp), C.byref(nnz)))
         return ("sparse" if sp.value else "dense"), int(nnz.value)
 
+    def mask_format(self):
+        """("lists" | "words", listed reporters): whether partial mask rows are also held as short reporter lists."""
+        li, n = C.c_int(), C.c_uint64()
+        self._check(self.lib.vmr_mask_format(self._h, C.byref(li), C.byref(n)))
+        return ("lists" if li.value else "words"), int(n.value)
+
     # -- measurement
     def profile(self, enable=True):
         self._check(self.lib.vmr_profile(self._h, int(enable)))
