@@ -201,6 +201,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
+        dist.barrier()   # rank 0 may still be in its (untimed) convergence fit
         dist.destroy_process_group()
 
 

@@ -157,6 +157,7 @@ def test_self_reporter_mask_lists_agree_with_mask_words(monkeypatch):
         c.cavi_step()
     e_cpu = c.elbo()
     out = {}
+    monkeypatch.setenv("VMR_FORMAT", "sparse")   # mask lists belong to the report-list format
     for mode in ("lists", "words"):
         if mode == "words":
             monkeypatch.setenv("VMR_NO_RLISTS", "1")

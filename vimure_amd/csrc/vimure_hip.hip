@@ -64,8 +64,9 @@ struct Geo {
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
   int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
+  int ecap;     // report lists: entries of a 64-tie step whose owners a wave resolves through its LDS map
   int dbg;      // timing experiments only (env VMR_DEBUG; results are wrong): dense path 1 = skip per-report math, 2 = skip
-                // the scan; report lists 8 = no H flush, 16 = no walk 2, 32 = no walk 1, 64 = no owner map, 128 = no per-tie update
+                // the scan; report lists 8 = no H flush
   double eps;
 };
 
@@ -86,7 +87,8 @@ struct vmr_ctx {
   // report lists (sparse format, see k_rho_sp); X is freed once they exist
   int sparse = 0;
   unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
-  unsigned* rp = nullptr;      // [L][N*N+1] first entry of a tie, relative to ebase[l]
+  unsigned* rp = nullptr;      // [L][N*N+1] exclusive scan of the ties' report counts, relative to ebase[l]
+  unsigned* tc = nullptr;      // [L][N*N] mutual reports of the tie | sum of its plain counts << 14
   unsigned* Qt = nullptr;      // [L][N*N] sum_m R[t,m] X[mirror(t),m]
   unsigned long long* ebase = nullptr;   // device [L]
   unsigned long long nnz = 0;  // non-zero counts in X
@@ -1159,7 +1161,6 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 // instead of the 1 B per (tie, reporter) of the dense layout, and no tile pair has to be staged: 4.5 GB -> 1.2 GB
 // per sweep at BASELINE config 3.  The dense tensor is freed once the lists exist.
 // ==========================================================================================
-#define SP_ECAP 1024   // entries of a wave's step (64 ties) whose owners are resolved through its LDS map
 #ifndef SP_PF
 #define SP_PF 4
 #endif
@@ -1176,21 +1177,56 @@ __device__ __forceinline__ unsigned nz_bytes(uint4 v) {
   return __popc(t0) + __popc(t1) + __popc(t2) + __popc(t3);
 }
 
-// non-zero counts per tie of one layer (16 lanes per row); the layer total goes to *nnz
+// per-byte mask: 0xff where the byte of w is non-zero
+__device__ __forceinline__ unsigned nz_mask(unsigned w) {
+  const unsigned M = 0x7f7f7f7fu;
+  const unsigned t = ((((w & M) + M) | w) >> 7) & 0x01010101u;
+  return t * 0xffu;
+}
+__device__ __forceinline__ unsigned byte_sum(unsigned w) {
+  return (w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24);
+}
+#define TC_N1(v) ((v) & 0x3fffu)   // reports of the tie whose mirror count is non-zero ("mutual" class)
+#define TC_X0(v) ((v) >> 14)       // sum of the counts of the other ("plain") reports
+
+// Per tie of one layer (16 lanes per row): rp[t] = non-zero counts n; tc[t] = n1 | X0 << 14, n1 = reports with a
+// non-zero mirror count, X0 = sum of the counts of the plain reports.  A tie whose X0 does not fit 18 bits keeps all
+// its reports in the mutual class (n1 = n, X0 = 0).  The layer total goes to *nnz.
+template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_count(const uint8_t* __restrict__ Xl, unsigned* __restrict__ rpl,
-                                                  unsigned long long* nnz, size_t T, int Mp) {
+                                                  unsigned* __restrict__ tcl, unsigned long long* nnz, Geo g) {
   __shared__ double red[8];
-  const int gl = threadIdx.x & 15, nchunk = Mp / 16;
+  const int gl = threadIdx.x & 15;
   unsigned long long mine = 0;
-  const size_t Tr = (T + 15) / 16 * 16;
+  const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
-    unsigned c = 0;
+    unsigned c = 0, c1 = 0, x0 = 0;
     if (t < T) {
-      const uint8_t* row = Xl + t * Mp;
-      for (int ch = gl; ch < nchunk; ch += 16) c += nz_bytes(*reinterpret_cast<const uint4*>(row + ch * 16));
+      const size_t i = t / g.N, j = t - i * g.N, tm = j * g.N + i;
+      const uint8_t* row = Xl + t * g.Mp;
+      const uint8_t* mrow = Xl + tm * g.Mp;
+      for (int ch = gl; ch < g.nchunk; ch += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + ch * 16);
+        if (!(v.x | v.y | v.z | v.w)) continue;
+        uint4 y = make_uint4(0, 0, 0, 0);
+        if (MUT) y = *reinterpret_cast<const uint4*>(mrow + ch * 16);
+        const unsigned xs[4] = {v.x, v.y, v.z, v.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned mx = nz_mask(xs[u]), my = nz_mask(ys[u]);
+          c += __popc(mx) >> 3;
+          c1 += __popc(mx & my) >> 3;
+          x0 += byte_sum(xs[u] & ~my);
+        }
+      }
     }
-    c = group_sum_u(c, 16);
-    if (gl == 0 && t < T) { rpl[t] = c; mine += c; }
+    c = group_sum_u(c, 16); c1 = group_sum_u(c1, 16); x0 = group_sum_u(x0, 16);
+    if (gl == 0 && t < T) {
+      if (x0 >= (1u << 18)) { c1 = c; x0 = 0; }
+      rpl[t] = c;
+      tcl[t] = c1 | (x0 << 14);
+      mine += c;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) rpl[T] = 0u;
   // block total (exact in double: < 2^53)
@@ -1244,11 +1280,15 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned* a, const unsigned* _
   for (int u = 0; u < 8; ++u) if (base + u < n) a[base + u] += add;
 }
 
-// write the entries of one layer (16 lanes per tie, in reporter order) and the mirror sums Qt
+// Write the entries of one layer (16 lanes per tie) and the mirror sums Qt.  Ties are grouped in steps of 64
+// consecutive ties (what one wave of k_rho_sp takes at a time); inside a step the PLAIN reports (mirror count 0) of
+// its ties come first, tie after tie, then the MUTUAL ones (tie after tie): the rho pass walks the two classes with
+// different arithmetic and wants each 64-entry trip to hold one class.  rpl is the exclusive scan of the per-tie
+// totals, so a step starts at rpl[64 s] and the class runs of a tie follow from the counts of the ties before it.
 template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
-                                                 const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
-                                                 unsigned* __restrict__ Qtl, Geo g) {
+                                                 const unsigned* __restrict__ rpl, const unsigned* __restrict__ tcl,
+                                                 unsigned* __restrict__ El, unsigned* __restrict__ Qtl, Geo g) {
   const int gl = threadIdx.x & 15;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
@@ -1259,25 +1299,51 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
     const uint8_t* mrow = Xl + tm * g.Mp;
     const uint64_t* rr = Rl + tc * g.W;
     const uint64_t* rmr = Rl + tm * g.W;
-    size_t pos = rpl[tc];
+    // where this tie's two runs start: plain reports of the step's earlier ties, all plain reports of the step
+    const size_t s0 = tc & ~(size_t)63;
+    const int pos_in_step = (int)(tc - s0);
+    unsigned before0 = 0, before1 = 0, tot0 = 0;
+    for (int u = gl; u < 64; u += 16) {
+      const size_t tt = s0 + u;
+      if (tt < T) {
+        const unsigned n_ = rpl[tt + 1] - rpl[tt], n1_ = TC_N1(tcl[tt]);
+        tot0 += n_ - n1_;
+        if (u < pos_in_step) { before0 += n_ - n1_; before1 += n1_; }
+      }
+    }
+    before0 = group_sum_u(before0, 16); before1 = group_sum_u(before1, 16); tot0 = group_sum_u(tot0, 16);
+    const unsigned n_all = rpl[tc + 1] - rpl[tc], n1_all = TC_N1(tcl[tc]);
+    const bool all_mutual = n1_all == n_all;   // (also the ties whose X0 did not fit)
+    size_t pos0 = (size_t)rpl[s0] + before0, pos1 = (size_t)rpl[s0] + tot0 + before1;
     unsigned q = 0;
     for (int c0 = 0; c0 < g.nchunk; c0 += 16) {   // uniform over the 16 lanes
       const int ch = c0 + gl;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok && ch < g.nchunk) v = *reinterpret_cast<const uint4*>(row + ch * 16);
-      const unsigned n = nz_bytes(v);
-      unsigned incl = n;
-#pragma unroll
-      for (int o2 = 1; o2 < 16; o2 <<= 1) {
-        unsigned up = __shfl_up(incl, o2, 16);
-        if (gl >= o2) incl += up;
+      uint4 v = make_uint4(0, 0, 0, 0), yv = make_uint4(0, 0, 0, 0);
+      if (ok && ch < g.nchunk) {
+        v = *reinterpret_cast<const uint4*>(row + ch * 16);
+        if (MUT) yv = *reinterpret_cast<const uint4*>(mrow + ch * 16);
       }
-      const unsigned tot = __shfl(incl, 15, 16);
-      size_t w = pos + incl - n;
-      const unsigned d[4] = {v.x, v.y, v.z, v.w};
+      const unsigned xs[4] = {v.x, v.y, v.z, v.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+      unsigned n = 0, n1 = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        unsigned dw = d[u];
+        const unsigned mx = nz_mask(xs[u]), my = nz_mask(ys[u]);
+        n += __popc(mx) >> 3;
+        n1 += __popc(mx & my) >> 3;
+      }
+      if (all_mutual) n1 = n;
+      const unsigned n0 = n - n1;
+      unsigned incl0 = n0, incl1 = n1;
+#pragma unroll
+      for (int o2 = 1; o2 < 16; o2 <<= 1) {
+        const unsigned up0 = __shfl_up(incl0, o2, 16), up1 = __shfl_up(incl1, o2, 16);
+        if (gl >= o2) { incl0 += up0; incl1 += up1; }
+      }
+      const unsigned t0_ = __shfl(incl0, 15, 16), t1_ = __shfl(incl1, 15, 16);
+      size_t w0 = pos0 + incl0 - n0, w1 = pos1 + incl1 - n1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        unsigned dw = xs[u];
         while (dw) {
           const int sh = __builtin_ctz(dw) & ~7;
           const unsigned x = (dw >> sh) & 0xffu;
@@ -1286,13 +1352,15 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
           const unsigned inr = (unsigned)((rr[m >> 6] >> (m & 63)) & 1ull);
           unsigned y = 0;
           if (MUT) {
-            y = mrow[m];
+            y = (ys[u] >> sh) & 0xffu;
             if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
           }
-          El[w++] = (unsigned)m | (inr << 13) | (x << 16) | (y << 24);
+          const unsigned ent = (unsigned)m | (inr << 13) | (x << 16) | (y << 24);
+          if (y != 0 || all_mutual) El[w1++] = ent; else El[w0++] = ent;
         }
       }
-      pos += tot;
+      pos0 += t0_;
+      pos1 += t1_;
     }
     q = group_sum_u(q, 16);
     if (ok && gl == 0) Qtl[tm] = q;   // every tie is the mirror of exactly one tie
@@ -1376,7 +1444,8 @@ __global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__
 }
 
 struct SpArgs {
-  const unsigned* E; const unsigned* rp; const unsigned long long* ebase; const uint64_t* Rb; const uint8_t* rcls;
+  const unsigned* E; const unsigned* rp; const unsigned* tc; const unsigned long long* ebase; const uint64_t* Rb;
+  const uint8_t* rcls;
   double* rho; const double* logpr; const double* par; double* slotR; const double* lutg; double* Hg; double* slotF;
   const unsigned* Qt;
   const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask lists (null: read the mask words)
@@ -1391,6 +1460,18 @@ struct SpArgs {
 // x * rho_new into H and collects the ELBO's log terms.  The waves of a workgroup share only the read-only tables
 // and the LDS levels of H, so the step loop has no workgroup barrier: waves drift apart and cover each other's
 // memory latency; the next step's values and entries are prefetched into registers.
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds only (no LDS traffic): shifts inside the 16-lane
+// rows, then the row totals are broadcast to the rows after them.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 // Orders a wave's LDS traffic across lanes: the LDS executes one wave's operations in issue order, so all that is
 // needed is that the compiler keeps them in program order.
 __device__ __forceinline__ void wave_sync() {
@@ -1399,12 +1480,15 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+#ifndef SP_LB
+#define SP_LB 1
+#endif
 template <int K, bool MUT, bool UPDATE, bool ELBO>
-__global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
+__global__ __launch_bounds__(TPB, SP_LB) void k_rho_sp(SpArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   size_t off = 0;
   // per reporter: E[log theta_m] and, with mutuality, cb_m = G_nu / G_theta_m beside it (one 16-byte LDS read per
-  // report; the weight's c[m,k] = G_nu / (G_theta_m G_lambda_k) = cb_m / G_lambda_k)
+  // mutual report; the weight's c[m,k] = G_nu / (G_theta_m G_lambda_k) = cb_m / G_lambda_k)
   double* tb = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * (MUT ? 16 : 8);
   double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
@@ -1415,21 +1499,26 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   // entry slot of a lane within a 64-entry trip: the (usually 2-8) consecutive entries of one tie go to lanes 32 / 16 / 48
   // apart, i.e. to different LDS service groups, so their adds to the tie's sum do not collide on one address
   const unsigned pl = ((unsigned)(lane & 15) << 2) | ((unsigned)(lane >> 5) & 1u) | ((((unsigned)lane >> 4) & 1u) << 1);
-  // wave-private: per-tie sums (U, then the tie's new rho; ELBO variants: exp(rho), and rho in rt) and the owner map
+  // wave-private: per-tie sums (U of the mutual reports, then the tie's new rho; ELBO variants: exp(rho), and rho in
+  // rt), the plain reports' sum s1 and the owner map
   double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)TPB * K * 8;
   double* rt = ELBO ? reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K : ut; off += ELBO ? (size_t)TPB * K * 8 : 0;
-  unsigned char* owner = smem + off + (size_t)wv * SP_ECAP;
+  double* s1 = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64; off += (size_t)TPB * 8;
+  unsigned char* owner = smem + off + (size_t)wv * g.ecap;
+  const unsigned ecap = (unsigned)g.ecap;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);   // steps of 64 ties; a workgroup owns a contiguous range, its waves interleave
-  const long long s0 = (long long)gb * NS / a.Gl, s1 = (long long)(gb + 1) * NS / a.Gl;
+  const long long s0 = (long long)gb * NS / a.Gl, s1_ = (long long)(gb + 1) * NS / a.Gl;
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  int bad = 0;   // a G_theta or G_lambda that underflowed to 0: its weight is 0 even for a plain report (den == 0 rule)
   for (int m = tid; m < g.Mp; m += TPB) {
     const double lt_ = a.par[o.l_th + (size_t)l * g.Mp + m], gt_ = a.par[o.G_th + (size_t)l * g.Mp + m];
     if (MUT) { tb[2 * m] = lt_; tb[2 * m + 1] = (gt_ == 0.0) ? (double)INFINITY : gnu / gt_; }
     else tb[m] = lt_;
     if (ELBO) Gth[m] = gt_;
+    if (MUT && m < g.M && gt_ == 0.0) bad = 1;
   }
   for (int q = tid; q < nHc; q += TPB) Hc[q] = 0.0;
   const double* lut = a.lutg + (size_t)l * g.W * 256;
@@ -1445,7 +1534,10 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   }
   double iGla[K];   // 1 / G_lambda_k (inf when it underflowed: the weight is then 0, the reference's den == 0 rule)
 #pragma unroll
-  for (int k = 0; k < K; ++k) iGla[k] = (Gla[k] == 0.0) ? (double)INFINITY : 1.0 / Gla[k];
+  for (int k = 0; k < K; ++k) {
+    iGla[k] = (Gla[k] == 0.0) ? (double)INFINITY : 1.0 / Gla[k];
+    if (MUT && Gla[k] == 0.0) bad = 1;
+  }
   const double eps = g.eps;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K];
@@ -1453,6 +1545,7 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
   const unsigned* rpl = a.rp + (size_t)l * (T + 1);
+  const unsigned* tcl = a.tc + (size_t)l * T;
   const unsigned* El = a.E + a.ebase[l];
   const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
   const uint8_t* cl = a.rcls + (size_t)l * T;
@@ -1465,7 +1558,7 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
 
   // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 entries of
   // the wave's next step and the entry range of the one after are in flight.
-  unsigned r0n = 0, r1n = 0, clsn = 0, qn = 0;
+  unsigned r0n = 0, r1n = 0, clsn = 0, qn = 0, tcn = 0;
   double lpn[K], rn[K];
   unsigned pen[SP_PF];
   unsigned ea1 = 0, eb1 = 0, ea2 = 0, eb2 = 0;
@@ -1480,6 +1573,7 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
     const bool ok = t < T;
     r0n = rpl[ok ? t : T];
     r1n = rpl[ok ? t + 1 : T];
+    tcn = ok ? tcl[t] : 0u;
     clsn = ok ? (a.all_full ? 1u : (unsigned)cl[t]) : 0u;
     if (ELBO && MUT) qn = ok ? Ql[t] : 0u;
 #pragma unroll
@@ -1496,19 +1590,57 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
     }
   };
   const long long sfirst = s0 + wv;
-  if (sfirst < s1) {
+  if (sfirst < s1_) {
     fetch_range(sfirst, ea1, eb1);
-    if (sfirst + TPB / 64 < s1) fetch_range(sfirst + TPB / 64, ea2, eb2);
+    if (sfirst + TPB / 64 < s1_) fetch_range(sfirst + TPB / 64, ea2, eb2);
     fetch_tie(sfirst, ea1, eb1);
   }
-  __syncthreads();   // tables
+  // plain reports take the short path only when no weight of the launch is forced to 0
+  const bool simple_ok = __syncthreads_or(bad) == 0;   // (also the barrier after the tables)
   double Tfull = 0.0;
   for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
 
-  for (long long s = sfirst; s < s1; s += TPB / 64) {
+  // per-report arithmetic
+  auto plain_val = [&](unsigned ent) -> double {   // x E[log theta_m]; the E[log lambda_k] x part is X0, a constant of the tie
+    const int m = ENT_M(ent);
+    return (double)ENT_X(ent) * tb[MUT ? 2 * m : m];
+  };
+  auto mutual_vals = [&](unsigned ent, double (&U)[K]) {   // (E log theta_m + E log lambda_k) x w1_k(m, y)
+    const int m = ENT_M(ent);
+    const double dx = (double)ENT_X(ent);
+    if (MUT) {
+      const double2 te = *reinterpret_cast<const double2*>(tb + 2 * m);
+      double w[K];
+      weights_cb<K>(w, te.y, iGla, ENT_Y(ent));
+#pragma unroll
+      for (int k = 0; k < K; ++k) U[k] = (te.x + lla[k]) * (dx * w[k]);
+    } else {
+      const double lt = tb[m];
+#pragma unroll
+      for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
+    }
+  };
+  auto stats_elbo = [&](unsigned ent, int ow, const double* rt_, const double* ut_) {   // walk 2, one report of tie ow
+    const int m = ENT_M(ent);
+    const unsigned y = ENT_Y(ent);
+    const double dx = (double)ENT_X(ent);
+    if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt_ + ow * K, (unsigned)g.hc);
+    if (ELBO) {
+      double inner = 0.0;
+      if (ENT_INR(ent)) {
+        const double z2 = gnu * (double)y, gt = Gth[m];
+        const double* er = ut_ + ow * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+      }
+      e_log += dx * log(inner + eps);
+    }
+  };
+
+  for (long long s = sfirst; s < s1_; s += TPB / 64) {
     const size_t t = (size_t)s * 64 + lane;
     const bool act = t < T;
-    const unsigned r0 = r0n, r1 = r1n, cls = clsn, qt = qn;
+    const unsigned r0 = r0n, r1 = r1n, cls = clsn, qt = qn, tcv = tcn;
     const unsigned ea = ea1, ne = eb1 - ea1;
     double lp[K], r[K];
     unsigned pe[SP_PF];
@@ -1521,24 +1653,30 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
       if (UPDATE) ut[lane * K + k] = 0.0;
       else { rt[lane * K + k] = r[k]; if (ELBO) ut[lane * K + k] = exp(r[k]); }
     }
-    // owner[]: the tie (lane) of every entry; a tie's lane fills its run, long runs are filled by the whole wave
-    auto build_owner = [&](unsigned e_first, bool mine) {
-      const unsigned n = mine ? r1 - r0 : 0u;
-      if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[r0 - e_first + q] = (unsigned char)lane;
+    if (UPDATE) s1[lane] = 0.0;
+    // the two runs of this lane's tie inside the step: plain reports first (all ties), then the mutual ones
+    const unsigned n_t = r1 - r0, n1_t = TC_N1(tcv);
+    const unsigned n0_t = n_t - n1_t;
+    const unsigned i0 = wave_incl_scan_u32(n0_t), i1 = wave_incl_scan_u32(n1_t);
+    const unsigned tot0 = __builtin_amdgcn_readlane((int)i0, 63);
+    const unsigned st0 = i0 - n0_t, st1 = tot0 + i1 - n1_t;   // run starts, relative to the step's first entry
+    // owner[]: the tie (lane) of every entry; a tie's lane fills its runs, long runs are filled by the whole wave
+    auto fill_run = [&](unsigned start, unsigned n) {
+      if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[start + q] = (unsigned char)lane;
       uint64_t hm = __ballot(n > 16u);
       while (hm) {
         const int hl = __builtin_ctzll(hm);
         hm &= hm - 1;
-        const unsigned s_h = __builtin_amdgcn_readlane((int)(r0 - e_first), hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
+        const unsigned s_h = __builtin_amdgcn_readlane((int)start, hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
         for (unsigned q = lane; q < n_h; q += 64) owner[s_h + q] = (unsigned char)hl;
       }
     };
-    const bool fast = ne <= SP_ECAP;   // the step's entries fit the owner map (always, in practice)
-    if (fast && !(g.dbg & 64)) build_owner(ea, true);
+    const bool fast = ne <= ecap;   // the step's entries fit the owner map (sized from the data's density)
+    if (fast) { fill_run(st0, n0_t); fill_run(st1, n1_t); }
     // next steps' loads
     ea1 = ea2; eb1 = eb2;
-    if (s + TPB / 64 < s1) {
-      if (s + 2 * (TPB / 64) < s1) fetch_range(s + 2 * (TPB / 64), ea2, eb2);
+    if (s + TPB / 64 < s1_) {
+      if (s + 2 * (TPB / 64) < s1_) fetch_range(s + 2 * (TPB / 64), ea2, eb2);
       fetch_tie(s + TPB / 64, ea1, eb1);
     }
     double Tt = 0.0;
@@ -1559,85 +1697,13 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
     }
     wave_sync();   // everything below is wave-local: LDS operations of a wave complete in order
 
-    auto walk1 = [&](unsigned e_first, unsigned nb_, bool pf, int single_tie) {
-      const int trips = (int)((nb_ + 63) / 64);
-      auto body = [&](unsigned ent, bool v, unsigned q) {
-        const int ow = single_tie >= 0 ? single_tie : (v ? (int)owner[q] : -1);
-        const int m = ENT_M(ent);
-        const double dx = (double)ENT_X(ent);
-        double U[K];
-        if (MUT) {
-          const double2 te = *reinterpret_cast<const double2*>(tb + 2 * m);
-          double w[K];
-          weights_cb<K>(w, te.y, iGla, ENT_Y(ent));
-#pragma unroll
-          for (int k = 0; k < K; ++k) U[k] = (te.x + lla[k]) * (dx * w[k]);
-        } else {
-          const double lt = tb[m];
-#pragma unroll
-          for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
-        }
-        const int o0 = __builtin_amdgcn_readfirstlane(ow);
-        if (__all(ow == o0 || !v)) {   // the whole wave is inside one tie: reduce, then one add per k
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const double sm_ = wave_sum(v ? U[k] : 0.0);
-            if (lane == 0) atomicAdd(&ut[o0 * K + k], sm_);
-          }
-        } else if (v) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
-        }
-      };
-#pragma unroll
-      for (int j = 0; j < SP_PF; ++j) {
-        const unsigned q = pl + (unsigned)j * 64;
-        if ((unsigned)j * 64 < nb_) {   // wave-uniform
-          const bool v = q < nb_;
-          body(pf ? pe[j] : (v ? El[(size_t)e_first + q] : 0u), v, q);
-        }
-      }
-      for (int j = SP_PF; j < trips; ++j) {
-        const unsigned q = pl + (unsigned)j * 64;
-        const bool v = q < nb_;
-        body(v ? El[(size_t)e_first + q] : 0u, v, q);
-      }
-    };
-    auto walk2 = [&](unsigned e_first, unsigned nb_, bool pf, int single_tie) {
-      const int trips = (int)((nb_ + 63) / 64);
-      auto body = [&](unsigned ent, unsigned q) {
-        const int ow = single_tie >= 0 ? single_tie : (int)owner[q];
-        const int m = ENT_M(ent);
-        const unsigned y = ENT_Y(ent);
-        const double dx = (double)ENT_X(ent);
-        if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt + ow * K, (unsigned)g.hc);
-        if (ELBO) {
-          double inner = 0.0;
-          if (ENT_INR(ent)) {
-            const double z2 = gnu * (double)y, gt = Gth[m];
-            const double* er = ut + ow * K;
-#pragma unroll
-            for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
-          }
-          e_log += dx * log(inner + eps);
-        }
-      };
-#pragma unroll
-      for (int j = 0; j < SP_PF; ++j) {
-        const unsigned q = pl + (unsigned)j * 64;
-        if (q < nb_) body(pf ? pe[j] : El[(size_t)e_first + q], q);
-      }
-      for (int j = SP_PF; j < trips; ++j) {
-        const unsigned q = pl + (unsigned)j * 64;
-        if (q < nb_) body(El[(size_t)e_first + q], q);
-      }
-    };
-    auto update_tie = [&](bool mine) {   // per-tie update from the finished sums
-      if (!mine) return;
+    auto update_tie = [&]() {   // per-tie update from the finished sums
+      const double x0 = simple_ok ? (double)TC_X0(tcv) : 0.0, sp = simple_ok ? s1[lane] : 0.0;
       double sum = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        r[k] = exp((lp[k] + ut[lane * K + k]) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
+        const double u = ut[lane * K + k] + (sp + lla[k] * x0);
+        r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
         sum += r[k];
       }
       if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
@@ -1651,8 +1717,8 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
         else ut[lane * K + k] = r[k];                                          // rt aliases ut
       }
     };
-    auto elbo_tie = [&](bool mine) {
-      if (!(ELBO && mine && act)) return;
+    auto elbo_tie = [&]() {
+      if (!(ELBO && act)) return;
       double sr = 0.0, se = 0.0, en = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -1665,37 +1731,118 @@ __global__ __launch_bounds__(TPB) void k_rho_sp(SpArgs a, Geo g) {
 
     if (fast) {
       if (UPDATE) {
-        if (!(g.dbg & 32)) walk1(ea, ne, true, -1);
-        wave_sync();
-        if (!(g.dbg & 128)) update_tie(true);
-        wave_sync();
-      }
-      if ((a.do_hist || ELBO) && !(g.dbg & 16)) walk2(ea, ne, true, -1);
-      elbo_tie(true);
-    } else {
-      // more entries than owner[] holds: batches of whole ties (a single tie with more than SP_ECAP entries is its
-      // own batch and needs no owner map)
-      int ta = 0;
-      while (ta < 64) {   // wave-uniform
-        const unsigned e_first = (unsigned)__builtin_amdgcn_readlane((int)r0, ta);
-        const uint64_t fit = __ballot(lane >= ta && r1 - e_first <= SP_ECAP);
-        const int cnt = __popcll(fit);
-        const bool single = cnt == 0;
-        const int tb = single ? ta + 1 : ta + cnt;
-        const unsigned nb_ = (unsigned)__builtin_amdgcn_readlane((int)r1, tb - 1) - e_first;
-        const bool mine = lane >= ta && lane < tb;
-        if (!single) { build_owner(e_first, mine); wave_sync(); }
-        if (UPDATE) {
-          walk1(e_first, nb_, false, single ? ta : -1);
-          wave_sync();
-          update_tie(mine);
-          wave_sync();
+        // walk 1: U of every tie.  Trips [0, tot0) hold plain reports (one multiply-add each), the rest mutual ones.
+        auto add_plain = [&](unsigned ent, int ow, bool p) {   // lanes with p: one plain report each
+          const double val = p ? plain_val(ent) : 0.0;
+          const int o0 = __builtin_amdgcn_readlane(ow, (int)__builtin_ctzll(__ballot(p)));
+          if (__all(ow == o0 || !p)) {   // all of them inside one tie: reduce, then one add
+            const double sm_ = wave_sum(val);
+            if (lane == 0) atomicAdd(&s1[o0], sm_);
+          } else if (p) {
+            atomicAdd(&s1[ow], val);
+          }
+        };
+        auto add_mutual = [&](unsigned ent, int ow, bool p) {
+          double U[K];
+          mutual_vals(ent, U);
+          const int o0 = __builtin_amdgcn_readlane(ow, (int)__builtin_ctzll(__ballot(p)));
+          if (__all(ow == o0 || !p)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const double sm_ = wave_sum(p ? U[k] : 0.0);
+              if (lane == 0) atomicAdd(&ut[o0 * K + k], sm_);
+            }
+          } else if (p) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
+          }
+        };
+        const unsigned nplain = simple_ok ? tot0 : 0u;   // entries [0, nplain) take the short path
+        auto trip = [&](unsigned ent, unsigned qb) {     // qb = first entry of the trip (wave-uniform)
+          const unsigned q = qb + pl;
+          const bool v = q < ne;
+          const int ow = v ? (int)owner[q] : -1;
+          if (qb + 64 <= nplain) add_plain(ent, ow, v);
+          else if (qb >= nplain) add_mutual(ent, ow, v);
+          else {   // the one trip that holds the class boundary
+            add_plain(ent, ow, v && q < nplain);
+            if (__any(v && q >= nplain)) add_mutual(ent, ow, v && q >= nplain);
+          }
+        };
+        const int trips = (int)((ne + 63) / 64);
+#pragma unroll
+        for (int j = 0; j < SP_PF; ++j) {
+          if ((unsigned)j * 64 < ne) trip(pe[j], (unsigned)j * 64);   // wave-uniform
         }
-        if (a.do_hist || ELBO) walk2(e_first, nb_, false, single ? ta : -1);
-        elbo_tie(mine);
-        ta = tb;
+        for (int j = SP_PF; j < trips; ++j) {
+          const unsigned q = pl + (unsigned)j * 64;
+          trip(q < ne ? El[(size_t)ea + q] : 0u, (unsigned)j * 64);
+        }
+        wave_sync();
+        update_tie();
         wave_sync();
       }
+      if (a.do_hist || ELBO) {   // walk 2: H of the (new) rho; ELBO log terms
+        const int trips = (int)((ne + 63) / 64);
+#pragma unroll
+        for (int j = 0; j < SP_PF; ++j) {
+          const unsigned q = pl + (unsigned)j * 64;
+          if (q < ne) stats_elbo(pe[j], (int)owner[q], rt, ut);
+        }
+        for (int j = SP_PF; j < trips; ++j) {
+          const unsigned q = pl + (unsigned)j * 64;
+          if (q < ne) stats_elbo(El[(size_t)ea + q], (int)owner[q], rt, ut);
+        }
+      }
+      elbo_tie();
+    } else {
+      // more entries than the owner map holds (a step far denser than the data's average): tie after tie, the whole
+      // wave on one tie's runs, sums through wave reductions
+      if (UPDATE) {
+        for (int ta = 0; ta < 64; ++ta) {   // wave-uniform
+          const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)st0, ta), c0 = (unsigned)__builtin_amdgcn_readlane((int)n0_t, ta);
+          const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)st1, ta), c1 = (unsigned)__builtin_amdgcn_readlane((int)n1_t, ta);
+          double sp = 0.0, U[K], Ua[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) Ua[k] = 0.0;
+          for (unsigned q = lane; q < c0; q += 64) {
+            const unsigned ent = El[(size_t)ea + b0 + q];
+            if (simple_ok) sp += plain_val(ent);
+            else {
+              mutual_vals(ent, U);
+#pragma unroll
+              for (int k = 0; k < K; ++k) Ua[k] += U[k];
+            }
+          }
+          for (unsigned q = lane; q < c1; q += 64) {
+            mutual_vals(El[(size_t)ea + b1 + q], U);
+#pragma unroll
+            for (int k = 0; k < K; ++k) Ua[k] += U[k];
+          }
+          if (c0 + c1) {
+            sp = wave_sum(sp);
+#pragma unroll
+            for (int k = 0; k < K; ++k) Ua[k] = wave_sum(Ua[k]);
+            if (lane == 0) {
+              s1[ta] = sp;
+#pragma unroll
+              for (int k = 0; k < K; ++k) ut[ta * K + k] = Ua[k];
+            }
+          }
+        }
+        wave_sync();
+        update_tie();
+        wave_sync();
+      }
+      if (a.do_hist || ELBO) {
+        for (int ta = 0; ta < 64; ++ta) {
+          const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)st0, ta), c0 = (unsigned)__builtin_amdgcn_readlane((int)n0_t, ta);
+          const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)st1, ta), c1 = (unsigned)__builtin_amdgcn_readlane((int)n1_t, ta);
+          for (unsigned q = lane; q < c0; q += 64) stats_elbo(El[(size_t)ea + b0 + q], ta, rt, ut);
+          for (unsigned q = lane; q < c1; q += 64) stats_elbo(El[(size_t)ea + b1 + q], ta, rt, ut);
+        }
+      }
+      elbo_tie();
     }
     wave_sync();
   }
@@ -2051,8 +2198,8 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
 }
 
 static size_t shmem_sp(const Geo& g, bool mut, bool elbo, bool hist) {
-  return (size_t)g.Mp * (mut ? 16 : 8) + (elbo ? 2 : 1) * (size_t)TPB * g.K * 8 + 64 +
-         (size_t)g.W * 8 + (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB / 64) * SP_ECAP;
+  return (size_t)g.Mp * (mut ? 16 : 8) + (elbo ? 2 : 1) * (size_t)TPB * g.K * 8 + (size_t)TPB * 8 + 64 +
+         (size_t)g.W * 8 + (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB / 64) * g.ecap;
 }
 
 struct Prof {
@@ -2143,7 +2290,7 @@ static int launch_hist(vmr_ctx* h) {
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
-    SpArgs a{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
+    SpArgs a{h->E, h->rp, h->tc, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
              h->rq, h->Rm, h->rbase, 1, h->all_full, 1};
     const size_t sm = shmem_sp(g, false, false, true);
     const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;   // at least one 64-tie step per wave
@@ -2257,7 +2404,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (mode != 2) h->h_zero = false;
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
-    SpArgs s{h->E, h->rp, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
+    SpArgs s{h->E, h->rp, h->tc, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
              h->rq, h->Rm, h->rbase, 1, h->all_full, (mode != 2 && !g.two_pass) ? 1 : 0};
     const size_t ssm = shmem_sp(g, g.mut != 0, mode != 0, s.do_hist != 0);
     const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
@@ -2318,6 +2465,7 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.hc = 0;
   g.two_pass = 0;
   g.fuse_full = 0;
+  g.ecap = 1024;
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
@@ -2425,13 +2573,19 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
       const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
       if (!force_dense && g.Mp <= 8192) {
         CCHK(hipMalloc(&h->rp, (size_t)L * (T + 1) * 4));
+        CCHK(hipMalloc(&h->tc, (size_t)L * T * 4));
         unsigned long long* nnz_dev = nullptr;
         CCHK(hipMalloc(&nnz_dev, (size_t)L * 8));
         CCHK(hipMemsetAsync(nnz_dev, 0, (size_t)L * 8, h->stream));
         const unsigned cgrid = (unsigned)std::min<size_t>(8192, (T + 15) / 16);
-        for (int l = 0; l < L; ++l)
-          hipLaunchKernelGGL(k_sp_count, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->rp + (size_t)l * (T + 1), nnz_dev + l, T, g.Mp);
+        for (int l = 0; l < L; ++l) {
+          if (g.mut)
+            hipLaunchKernelGGL(k_sp_count<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                               h->rp + (size_t)l * (T + 1), h->tc + (size_t)l * T, nnz_dev + l, g);
+          else
+            hipLaunchKernelGGL(k_sp_count<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                               h->rp + (size_t)l * (T + 1), h->tc + (size_t)l * T, nnz_dev + l, g);
+        }
         CCHK(hipGetLastError());
         CCHK(hipStreamSynchronize(h->stream));   // the stream is non-blocking: a plain hipMemcpy does not wait for it
         std::vector<unsigned long long> nl(L), eb(L);
@@ -2442,6 +2596,12 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
         for (int l = 0; l < L; ++l) { eb[l] = h->nnz; h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
         const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
         h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
+        {   // owner map of a wave: 1.5 x the average entries of a 64-tie step (denser steps are walked tie by tie)
+          const double per_step = 64.0 * (double)h->nnz / (double)rows;
+          long long ec = (long long)(1.5 * per_step / 256.0 + 1.0) * 256;
+          if (const char* fe = getenv("VMR_ECAP")) ec = atoll(fe);
+          g.ecap = (int)std::min<long long>(8192, std::max<long long>(1024, ec));
+        }
         if (h->sparse) {
           const size_t n = T + 1;
           const unsigned nbs = (unsigned)((n + 2047) / 2048);
@@ -2462,10 +2622,10 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
           for (int l = 0; l < L; ++l) {
             if (g.mut)
               hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->E + eb[l], h->Qt + (size_t)l * T, g);
+                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->tc + (size_t)l * T, h->E + eb[l], h->Qt + (size_t)l * T, g);
             else
               hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->E + eb[l], h->Qt + (size_t)l * T, g);
+                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->tc + (size_t)l * T, h->E + eb[l], h->Qt + (size_t)l * T, g);
           }
           CCHK(hipGetLastError());
           CCHK(hipStreamSynchronize(h->stream));
@@ -2521,7 +2681,9 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
           if (!getenv("VMR_KEEP_X")) { CCHK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
         } else {
           CCHK(hipFree(h->rp));
+          CCHK(hipFree(h->tc));
           h->rp = nullptr;
+          h->tc = nullptr;
         }
       } else if (force_sparse) {
         vmr_destroy(h);
@@ -2583,7 +2745,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rp, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rp, h->tc, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -2850,7 +3012,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   const double SX = V, SR = V / 8.0, Srho = 8.0 * g.L * (double)g.N * g.N * g.K;
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
-    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties + g.L);
+    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties + g.L) + 4.0 * ties;   // entries; row pointers + class record
     const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {
