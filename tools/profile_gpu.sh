@@ -4,7 +4,7 @@
 # FETCH_SIZE and WRITE_SIZE do not fit one pass), never combined with sys/runtime tracing.
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/pmc_summary.py turns them into profiles/.
 set -o pipefail
-TAG=${1:-r01b}
+TAG=${1:-r01c}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
