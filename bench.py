@@ -69,11 +69,15 @@ def main():
     ap.add_argument("--no-converge", action="store_true", help="skip the time-to-ELBO-converge fit")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (fresh child processes under
+        # torch.distributed.run; this process never touches the GPU) and hand back their exit code
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
@@ -203,6 +207,26 @@ def main():
     if dist is not None:
         dist.barrier()   # rank 0 may still be in its (untimed) convergence fit
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N ranks, one per GPU, over RCCL.  Refuses (exit code 2) when the
+    node has fewer than N devices; never re-execs a process that has initialised the GPU (device_count() does not)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node has {have} GPU(s); refusing to report a {n}-GPU number", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def time_to_converge(cfg, net, eng, seed):

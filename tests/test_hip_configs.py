@@ -1,0 +1,172 @@
+"""GPU parity at the sizes BASELINE.json states (configs[1], configs[2]) and in the config-5 regime (M = 1000, K = 3),
+against the CPU oracles on the same seeded inputs and initial state:
+
+  configs[1]  L=1 N=500 M=50 K=2, mutuality off, R = None and R = ones, both data layouts   -> oracle/cavi_ref.c
+  configs[2]  L=4 N=2000 M=200 K=2, mutuality on, full fit to the reference's stop rule       -> oracle/cavi_coo.c
+  configs[4]  one layer N=1500 M=1000 K=3 in each mode the engine has for wide reporter dimensions -> oracle/cavi_coo.c
+
+The coordinate-list oracle is used where a dense [L,N,N,M] host tensor is out of reach; it is pinned to the
+reference's golden vectors and to the dense oracle in tests/test_coo_oracle.py."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PRI = (0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+
+
+def _host_state(L, N, M, K, mutuality, seed, sum_x, coverage):
+    """RandomState-exact initial state through the host class (reference model.py:458-605)."""
+    from vimure_amd.model import VimureModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel(mutuality=mutuality)
+    m.L, m.N, m.M, m.K = L, N, M, K
+    m.alpha_theta, m.beta_theta, m.alpha_lambda, m.beta_lambda, m.alpha_mutuality, m.beta_mutuality = PRI
+    m.rho_prior = None
+    m._change_seed(seed)
+    pr = m._draw_pr_rho(coverage, 0.0)
+    m._draw_gammas(sum_x)
+    return (m.gamma_shp, m.gamma_rte, m.phi_shp, m.phi_rte, m.nu_shp, m.nu_rte, pr)
+
+
+def _coo_from_device(X):
+    """Non-zero counts of a device tensor [L,N,N,M] as host (subs, vals), one layer and row block at a time."""
+    import torch
+    L, N, _, M = X.shape
+    subs, vals = [[], [], [], []], []
+    step = max(1, int(2.5e8 // (N * M)))
+    for l in range(L):
+        for i0 in range(0, N, step):
+            blk = X[l, i0:i0 + step]
+            nz = torch.nonzero(blk, as_tuple=True)
+            subs[0].append(np.full(len(nz[0]), l, np.int64))
+            subs[1].append((nz[0] + i0).cpu().numpy())
+            subs[2].append(nz[1].cpu().numpy())
+            subs[3].append(nz[2].cpu().numpy())
+            vals.append(blk[nz].cpu().numpy())
+    return tuple(np.concatenate(a) for a in subs), np.concatenate(vals)
+
+
+def _assert_state(st, c, elbo_gpu, elbo_cpu, rho_rtol=1e-7):
+    assert abs(elbo_gpu - elbo_cpu) <= 1e-9 * max(1.0, abs(elbo_cpu)), (elbo_gpu, elbo_cpu)
+    np.testing.assert_allclose(st["rho"], c.rho, rtol=rho_rtol, atol=1e-12)
+    for n in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte"):
+        np.testing.assert_allclose(st[n], getattr(c, n), rtol=1e-9, err_msg=n)
+    np.testing.assert_allclose(st["nu_shp"], c.nu_shp, rtol=1e-9)
+
+
+@pytest.mark.parametrize("mask", ["none", "ones"])
+def test_config2_full_size_mutuality_off(mask, vmr_format):
+    """BASELINE configs[1] at its stated size; the reference needs 2.09 s per sweep + 20.8 s per ELBO here."""
+    from oracle import cavi_ref
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    L, N, M, K = 1, 500, 50, 2
+    net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.0, seed=0)
+    R = None if mask == "none" else np.ones((L, N, N, M), np.uint8)
+    eng = CaviEngine(net.X, R, K=K, mutuality=False)
+    assert eng.data_format()[0] == vmr_format
+    sum_x, cov = eng.data_stats()
+    init = _host_state(L, N, M, K, False, 1, sum_x, cov)
+    c = cavi_ref.CRef(net.X, R, K, False, PRI, *init)
+    eng.set_priors(*PRI)
+    eng.set_state(*init)
+    for it in range(1, 13):
+        c.cavi_step()
+        e = eng.step(1, want_elbo=(it in (1, 10, 12)))
+        if e is not None:
+            e_cpu = c.elbo()
+            # mutuality off: the ELBO carries the constant -5e5 of the nu term: absolute bound
+            assert abs(e - e_cpu) <= 1e-6, (it, e, e_cpu)
+    _assert_state(eng.get_state(), c, e, e_cpu)
+    assert abs(eng.elbo() - e_cpu) <= 1e-6
+    eng.close()
+
+
+def test_config3_full_size_fit_stops_where_the_oracle_stops():
+    """BASELINE configs[2] (the benchmarked configuration): the engine and the oracle, from the same start, evaluate
+    the same ELBOs at iterations 1, 10, 20, ... and the reference's stop rule (model.py:1036-1056) fires at the same
+    iteration; `VimureModel.fit` on the same engine reports that iteration in its trace."""
+    import torch
+    from oracle import cavi_coo
+    from vimure_amd import CaviEngine, VimureModel
+    from vimure_amd.synthetic import standard_sbm
+    L, N, M, K = 4, 2000, 200, 2
+    net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.5, seed=0, device="cuda:0")
+    eng = CaviEngine(net.X, None, K=K, mutuality=True, device=0)
+    assert eng.data_format()[0] == "sparse"
+    sum_x, cov = eng.data_stats()
+    seed = 1
+    init = _host_state(L, N, M, K, True, seed, sum_x, cov)
+    subs, vals = _coo_from_device(net.X)
+    assert eng.data_format()[1] == len(vals)
+    c = cavi_coo.CooRef((subs, vals), None, (L, N, N, M), K, True, PRI, *init)
+    eng.set_priors(*PRI)
+    eng.set_state(*init)
+    coincide = [0, 0]
+    old = [-1e10, -1e10]
+    stop = [None, None]
+    checks = []
+    for it in range(1, 201):
+        check = it == 1 or it % 10 == 0
+        e_gpu = eng.step(1, want_elbo=check)
+        c.cavi_step()
+        if check:
+            e_cpu = c.elbo()
+            checks.append((it, e_gpu, e_cpu))
+            assert abs(e_gpu - e_cpu) <= 1e-9 * abs(e_cpu), (it, e_gpu, e_cpu)
+            for w, e in enumerate((e_gpu, e_cpu)):
+                coincide[w] = coincide[w] + 1 if abs(e - old[w]) < 0.1 else 0
+                old[w] = e
+                if coincide[w] > 1 and stop[w] is None:
+                    stop[w] = it
+        if stop[0] is not None or stop[1] is not None:
+            break
+    assert stop[0] is not None and stop[0] == stop[1], (stop, checks)
+    _assert_state(eng.get_state(), c, checks[-1][1], checks[-1][2], rho_rtol=1e-6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VimureModel(mutuality=True).fit(net.X, K=K, seed=seed, engine=eng, num_realisations=1, max_iter=500)
+    assert int(m.trace["iter"].max()) == stop[1] and bool(m.trace["reached_convergence"].iloc[-1])
+    assert abs(m.maxL - checks[-1][2]) <= 1e-9 * abs(checks[-1][2])
+    eng.close()
+    del net
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["default", "three_levels_two_passes", "tie_by_tie_walk"])
+def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
+    """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): the statistics H do
+    not fit in LDS beside the rho pass' tables, so the engine either keeps two levels there (default), or rebuilds H in
+    a second pass (VMR_HC=3), and steps denser than the owner map are walked tie by tie (VMR_ECAP=1024 forces it)."""
+    import torch
+    from oracle import cavi_coo
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    if mode == "three_levels_two_passes":
+        monkeypatch.setenv("VMR_HC", "3")
+    elif mode == "tie_by_tie_walk":
+        monkeypatch.setenv("VMR_ECAP", "1024")
+    L, N, M, K = 1, 1500, 1000, 3
+    net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.5, seed=2, device="cuda:0")
+    eng = CaviEngine(net.X, None, K=K, mutuality=True, device=0)
+    assert eng.data_format()[0] == "sparse"
+    sum_x, cov = eng.data_stats()
+    init = _host_state(L, N, M, K, True, 3, sum_x, cov)
+    subs, vals = _coo_from_device(net.X)
+    c = cavi_coo.CooRef((subs, vals), None, (L, N, N, M), K, True, PRI, *init)
+    eng.set_priors(*PRI)
+    eng.set_state(*init)
+    for it in range(1, 4):
+        c.cavi_step()
+        e = eng.step(1, want_elbo=True)
+        e_cpu = c.elbo()
+        assert abs(e - e_cpu) <= 1e-9 * abs(e_cpu), (it, e, e_cpu)
+    _assert_state(eng.get_state(), c, e, e_cpu)
+    assert abs(eng.elbo() - e_cpu) <= 1e-9 * abs(e_cpu)
+    eng.close()
+    del net
+    torch.cuda.empty_cache()

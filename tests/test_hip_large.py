@@ -10,7 +10,7 @@ from oracle import vimure_oracle as vo
 pytestmark = pytest.mark.gpu
 
 
-def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2):
+def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2, fmt=None):
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
     net = standard_sbm(N=N, M=M, L=L, K=K, avg_degree=5.0, eta=eta, seed=0)
@@ -37,6 +37,8 @@ def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2):
     nu_s, nu_r = (0.5 * prng.random_sample(1)[0] + 0.5, 1.0 + float(X.sum())) if mutuality else (1e-6, 1.0)
     c = cavi_ref.CRef(X, R, K, mutuality, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), gs, gr, ps, prt, nu_s, nu_r, pr_rho)
     eng = CaviEngine(X, R, K=K, mutuality=mutuality)
+    if fmt is not None:
+        assert eng.data_format()[0] == fmt   # the layout under test is the one that runs
     s, cov = eng.data_stats()
     assert s == float(X.sum()) and np.array_equal(cov.astype(bool), pb_cov)
     eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
@@ -61,32 +63,32 @@ def _run(L, N, M, K, eta, mutuality, mask, sweeps=3, seed=2):
     eng.close()
 
 
-def test_m200_mutuality_all_ones_mask():
-    _run(L=2, N=333, M=200, K=2, eta=0.5, mutuality=True, mask="ones")     # ragged tiles: 333 = 41*8 + 5
+def test_m200_mutuality_all_ones_mask(vmr_format):
+    _run(L=2, N=333, M=200, K=2, eta=0.5, mutuality=True, mask="ones", fmt=vmr_format)     # ragged tiles: 333 = 41*8 + 5
 
 
-def test_m200_random_mask_k3():
-    _run(L=1, N=250, M=200, K=3, eta=0.4, mutuality=True, mask="random")
+def test_m200_random_mask_k3(vmr_format):
+    _run(L=1, N=250, M=200, K=3, eta=0.4, mutuality=True, mask="random", fmt=vmr_format)
 
 
-def test_m1000_tile_edge4_no_mutuality():
-    _run(L=1, N=90, M=1000, K=2, eta=0.0, mutuality=False, mask="random", sweeps=2)   # b = 4, 16 mask words
+def test_m1000_tile_edge4_no_mutuality(vmr_format):
+    _run(L=1, N=90, M=1000, K=2, eta=0.0, mutuality=False, mask="random", sweeps=2, fmt=vmr_format)   # b = 4, 16 mask words
 
 
-def test_mixed_mask_rows_full_empty_partial():
-    _run(L=2, N=120, M=100, K=2, eta=0.5, mutuality=True, mask="mixed", sweeps=4)
+def test_mixed_mask_rows_full_empty_partial(vmr_format):
+    _run(L=2, N=120, M=100, K=2, eta=0.5, mutuality=True, mask="mixed", sweeps=4, fmt=vmr_format)
 
 
-def test_m2000_tile_edge2():
-    _run(L=1, N=40, M=2000, K=2, eta=0.5, mutuality=True, mask="random", sweeps=2)     # b = 2, 32 lanes per tie
+def test_m2000_tile_edge2(vmr_format):
+    _run(L=1, N=40, M=2000, K=2, eta=0.5, mutuality=True, mask="random", sweeps=2, fmt=vmr_format)     # b = 2, 32 lanes per tie
 
 
-def test_m7000_tile_edge1_chunk_walk():
-    _run(L=1, N=20, M=7000, K=2, eta=0.0, mutuality=False, mask="ones", sweeps=2)      # b = 1, 64 lanes per tie
+def test_m7000_tile_edge1_chunk_walk(vmr_format):
+    _run(L=1, N=20, M=7000, K=2, eta=0.0, mutuality=False, mask="ones", sweeps=2, fmt=vmr_format)      # b = 1, 64 lanes per tie
 
 
-def test_m4000_mutuality_tables_fill_lds():
-    _run(L=1, N=24, M=4000, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2)     # ~150 KB of LDS tables
+def test_m4000_mutuality_tables_fill_lds(vmr_format):
+    _run(L=1, N=24, M=4000, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2, fmt=vmr_format)     # ~150 KB of LDS tables
 
 
 def test_reporter_tables_beyond_lds_are_refused():
@@ -96,16 +98,50 @@ def test_reporter_tables_beyond_lds_are_refused():
         CaviEngine(X, None, K=2, mutuality=True)
 
 
-def test_k5_categories():
-    _run(L=1, N=150, M=64, K=5, eta=0.5, mutuality=True, mask="mixed", sweeps=3)
+def test_m8300_beyond_the_list_format_uses_dense_tiles(monkeypatch):
+    """Report lists hold the reporter in 13 bits (M <= 8192); wider tensors stay on the dense tiles."""
+    monkeypatch.delenv("VMR_FORMAT", raising=False)
+    _run(L=1, N=10, M=8300, K=2, eta=0.0, mutuality=False, mask="random", sweeps=2, fmt="dense")
 
 
-def test_m1000_k3_mutuality_two_lds_levels():
-    _run(L=1, N=60, M=1000, K=3, eta=0.5, mutuality=True, mask="ones", sweeps=2)       # H levels 0-1 in LDS beside the rho pass
+def test_wide_self_reporter_mask_falls_back_to_mask_words(monkeypatch):
+    """Mask lists need A[Mp][K] in LDS (k_mask_lists); M = 3000 with K = 8 does not fit, the mask words take over."""
+    from vimure_amd import CaviEngine
+    monkeypatch.setenv("VMR_FORMAT", "sparse")
+    N = M = 3000
+    X = np.zeros((1, 6, 6, M), np.uint8)   # N must equal M only for the mask's meaning, not for the engine
+    R = np.zeros((1, 6, 6, M), np.uint8)
+    for i in range(6):
+        for j in range(6):
+            R[0, i, j, [i, j]] = 1
+            if i != j:
+                X[0, i, j, i] = 1 + (i + j) % 3
+    eng = CaviEngine(X, R, K=8, mutuality=False)
+    assert eng.mask_format()[0] == "words"
+    g = np.random.RandomState(0)
+    pr = 1.0 + 0.01 * g.rand(1, 6, 6, 8)
+    pr /= pr.sum(-1)[..., None]
+    init = (0.1 + 0.1 * g.rand(1, M), 0.1 + 0.1 * g.rand(1, M), 10 + 10 * g.rand(1, 8), 10 + 10 * g.rand(1, 8), 1e-6, 1.0, pr)
+    c = cavi_ref.CRef(X, R, 8, False, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), *init)
+    eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+    eng.set_state(*init)
+    e = eng.step(2, want_elbo=True)
+    c.cavi_step(); c.cavi_step()
+    assert abs(e - c.elbo()) <= 1e-9 * abs(c.elbo())
+    np.testing.assert_allclose(eng.get_state()["rho"], c.rho, rtol=1e-8, atol=1e-13)
+    eng.close()
 
 
-def test_m1500_k4_statistics_in_a_second_pass():
-    _run(L=1, N=40, M=1500, K=4, eta=0.5, mutuality=True, mask="random", sweeps=2)     # tables too wide: two passes per sweep
+def test_k5_categories(vmr_format):
+    _run(L=1, N=150, M=64, K=5, eta=0.5, mutuality=True, mask="mixed", sweeps=3, fmt=vmr_format)
+
+
+def test_m1000_k3_mutuality_two_lds_levels(vmr_format):
+    _run(L=1, N=60, M=1000, K=3, eta=0.5, mutuality=True, mask="ones", sweeps=2, fmt=vmr_format)       # H levels 0-1 in LDS beside the rho pass
+
+
+def test_m1500_k4_statistics_in_a_second_pass(vmr_format):
+    _run(L=1, N=40, M=1500, K=4, eta=0.5, mutuality=True, mask="random", sweeps=2, fmt=vmr_format)     # tables too wide: two passes per sweep
 
 
 def test_dense_and_report_list_formats_agree(monkeypatch):
@@ -176,8 +212,8 @@ def test_self_reporter_mask_lists_agree_with_mask_words(monkeypatch):
     assert abs(out["lists"][0] - out["words"][0]) <= 1e-11 * abs(e_cpu)
 
 
-def test_m50_small_rows():
-    _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones")
+def test_m50_small_rows(vmr_format):
+    _run(L=3, N=200, M=50, K=2, eta=0.5, mutuality=True, mask="ones", fmt=vmr_format)
 
 
 def test_subnormal_normaliser_is_divided_not_inverted():

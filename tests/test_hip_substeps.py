@@ -1,6 +1,6 @@
 """GPU parity, step level: every CAVI sub-step and the ELBO of the HIP engine (through the
 C-ABI) against (a) the CPU oracle on the same seeded inputs and (b) the golden vectors dumped
-from the reference.  Tolerances: relative 1e-9 on gamma/phi/nu, 1e-9 rel + 1e-13 abs on rho,
+from the reference, in both data layouts of the engine (report lists and dense tiles).  Tolerances: relative 1e-9 on gamma/phi/nu, 1e-9 rel + 1e-13 abs on rho,
 1e-10 relative on the ELBO (north_star asks 1e-5 / 1e-6)."""
 import numpy as np
 import pytest
@@ -28,8 +28,9 @@ def _setup(name):
 
 
 @pytest.mark.parametrize("name", case_names())
-def test_data_stats(name):
+def test_data_stats(name, vmr_format):
     d, pb, st, eng = _setup(name)
+    assert eng.data_format()[0] == vmr_format
     s, cov = eng.data_stats()
     assert s == pb.sumX
     expect = (pb.R.any(axis=3) & (pb.X != 0).any(axis=3)).astype(np.uint8)
@@ -38,7 +39,7 @@ def test_data_stats(name):
 
 
 @pytest.mark.parametrize("name", case_names())
-def test_substeps_match_oracle_and_golden(name):
+def test_substeps_match_oracle_and_golden(name, vmr_format):
     from vimure_amd import _lib
     d, pb, st, eng = _setup(name)
     n_it = len(d["step_elbo"])
@@ -72,7 +73,7 @@ def test_substeps_match_oracle_and_golden(name):
 
 
 @pytest.mark.parametrize("name", ["A_ones_mut", "B_random_mask_K3", "C_ones_nomut", "D_self_mask"])
-def test_fused_step_equals_substeps(name):
+def test_fused_step_equals_substeps(name, vmr_format):
     """vmr_step (fused sweep, ELBO reduced inside the rho pass) == the four sub-steps + stand-alone ELBO."""
     d, pb, st, eng = _setup(name)
     e_fused = eng.step(1, want_elbo=True)

@@ -2655,7 +2655,7 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
             for (int l = 0; l < L; ++l) { rb_[l] = h->n_rm; h->n_rm += rl_[l]; ok32 = ok32 && rl_[l] < 0xffffffffull; }
             // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row)
             const double list_bytes = 2.0 * (double)h->n_rm + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
-            if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes) {
+            if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024) {   // (A[Mp][K] of k_mask_lists lives in LDS)
               for (int l = 0; l < L; ++l) {
                 unsigned* rql = h->rq + (size_t)l * n;
                 hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rql, bsum, n);
@@ -2757,12 +2757,13 @@ void vmr_destroy(vmr_handle h) {
 int vmr_data_stats(vmr_handle h, double* sum_x, uint8_t* coverage) {
   if (!h) return VMR_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  if (sum_x) {
-    unsigned long long v = 0;
-    HIPCHK(h, hipMemcpy(&v, h->sumx, 8, hipMemcpyDeviceToHost));
-    *sum_x = (double)v;
-  }
-  if (coverage) HIPCHK(h, hipMemcpy(coverage, h->cov, (size_t)h->g.L * h->g.N * h->g.N, hipMemcpyDeviceToHost));
+  // every copy is ordered on the handle's stream: it is a non-blocking stream, which plain hipMemcpy (null stream)
+  // does not wait for
+  unsigned long long v = 0;
+  if (sum_x) HIPCHK(h, hipMemcpyAsync(&v, h->sumx, 8, hipMemcpyDeviceToHost, h->stream));
+  if (coverage) HIPCHK(h, hipMemcpyAsync(coverage, h->cov, (size_t)h->g.L * h->g.N * h->g.N, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (sum_x) *sum_x = (double)v;
   return VMR_OK;
 }
 
@@ -2772,7 +2773,17 @@ static int upload_lm(vmr_ctx* h, size_t off, const double* src, double pad) {
   std::vector<double> buf((size_t)g.L * g.Mp, pad);
   for (int l = 0; l < g.L; ++l) memcpy(&buf[(size_t)l * g.Mp], src + (size_t)l * g.M, (size_t)g.M * 8);
   HIPCHK(h, hipMemcpyAsync(h->par + off, buf.data(), buf.size() * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // buf is a pageable temporary: it must outlive the copy
+  return VMR_OK;
+}
+// small host -> device copy ordered on the handle's stream (the stream is non-blocking: a null-stream hipMemcpy
+// would not wait for kernels queued on it)
+static int h2d(vmr_ctx* h, void* dst, const void* src, size_t n) {
+  HIPCHK(h, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, h->stream));
+  return VMR_OK;
+}
+static int d2h(vmr_ctx* h, void* dst, const void* src, size_t n) {
+  HIPCHK(h, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream));
   return VMR_OK;
 }
 
@@ -2785,10 +2796,11 @@ int vmr_set_priors(vmr_handle h, const double* alpha_theta, const double* beta_t
   int rc;
   if ((rc = upload_lm(h, o.a_th, alpha_theta, 1.0))) return rc;
   if ((rc = upload_lm(h, o.b_th, beta_theta, 1.0))) return rc;
-  HIPCHK(h, hipMemcpy(h->par + o.a_la, alpha_lambda, (size_t)g.L * g.K * 8, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->par + o.b_la, beta_lambda, (size_t)g.L * g.K * 8, hipMemcpyHostToDevice));
+  if ((rc = h2d(h, h->par + o.a_la, alpha_lambda, (size_t)g.L * g.K * 8))) return rc;
+  if ((rc = h2d(h, h->par + o.b_la, beta_lambda, (size_t)g.L * g.K * 8))) return rc;
   double ab[2] = {alpha_eta, beta_eta};
-  HIPCHK(h, hipMemcpy(h->par + o.sc + SC_A_ETA, ab, 16, hipMemcpyHostToDevice));
+  if ((rc = h2d(h, h->par + o.sc + SC_A_ETA, ab, 16))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_priors = true;
   return VMR_OK;
 }
@@ -2803,10 +2815,10 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   int rc;
   if ((rc = upload_lm(h, o.g_shp, gamma_shp, 1.0))) return rc;
   if ((rc = upload_lm(h, o.g_rte, gamma_rte, 1.0))) return rc;
-  HIPCHK(h, hipMemcpy(h->par + o.p_shp, phi_shp, (size_t)g.L * g.K * 8, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->par + o.p_rte, phi_rte, (size_t)g.L * g.K * 8, hipMemcpyHostToDevice));
+  if ((rc = h2d(h, h->par + o.p_shp, phi_shp, (size_t)g.L * g.K * 8))) return rc;
+  if ((rc = h2d(h, h->par + o.p_rte, phi_rte, (size_t)g.L * g.K * 8))) return rc;
   double nu[2] = {nu_shp, nu_rte};
-  HIPCHK(h, hipMemcpy(h->par + o.sc + SC_NU_SHP, nu, 16, hipMemcpyHostToDevice));
+  if ((rc = h2d(h, h->par + o.sc + SC_NU_SHP, nu, 16))) return rc;   // (the stream is synchronised below, before nu[] dies)
   const size_t n = (size_t)g.L * g.N * g.N * g.K;
   const double* src = pr_rho;
   if (!pr_rho_on_device) {
@@ -2916,7 +2928,8 @@ int vmr_sub_step(vmr_handle h, int which) {
 static int download_lm(vmr_ctx* h, size_t off, double* dst) {
   const Geo& g = h->g;
   std::vector<double> buf((size_t)g.L * g.Mp);
-  HIPCHK(h, hipMemcpy(buf.data(), h->par + off, buf.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpyAsync(buf.data(), h->par + off, buf.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int l = 0; l < g.L; ++l) memcpy(dst + (size_t)l * g.M, &buf[(size_t)l * g.Mp], (size_t)g.M * 8);
   return VMR_OK;
 }
@@ -2931,11 +2944,12 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
   int rc;
   if (gamma_shp && (rc = download_lm(h, o.g_shp, gamma_shp))) return rc;
   if (gamma_rte && (rc = download_lm(h, o.g_rte, gamma_rte))) return rc;
-  if (phi_shp) HIPCHK(h, hipMemcpy(phi_shp, h->par + o.p_shp, (size_t)g.L * g.K * 8, hipMemcpyDeviceToHost));
-  if (phi_rte) HIPCHK(h, hipMemcpy(phi_rte, h->par + o.p_rte, (size_t)g.L * g.K * 8, hipMemcpyDeviceToHost));
-  if (nu_shp) HIPCHK(h, hipMemcpy(nu_shp, h->par + o.sc + SC_NU_SHP, 8, hipMemcpyDeviceToHost));
-  if (nu_rte) HIPCHK(h, hipMemcpy(nu_rte, h->par + o.sc + SC_NU_RTE, 8, hipMemcpyDeviceToHost));
-  if (rho) HIPCHK(h, hipMemcpy(rho, h->rho, (size_t)g.L * g.N * g.N * g.K * 8, hipMemcpyDeviceToHost));
+  if (phi_shp && (rc = d2h(h, phi_shp, h->par + o.p_shp, (size_t)g.L * g.K * 8))) return rc;
+  if (phi_rte && (rc = d2h(h, phi_rte, h->par + o.p_rte, (size_t)g.L * g.K * 8))) return rc;
+  if (nu_shp && (rc = d2h(h, nu_shp, h->par + o.sc + SC_NU_SHP, 8))) return rc;
+  if (nu_rte && (rc = d2h(h, nu_rte, h->par + o.sc + SC_NU_RTE, 8))) return rc;
+  if (rho && (rc = d2h(h, rho, h->rho, (size_t)g.L * g.N * g.N * g.K * 8))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return VMR_OK;
 }
 
@@ -2947,9 +2961,10 @@ int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g
   ParOff o = par_off(g.L, g.Mp, g.K);
   int rc;
   if (g_theta && (rc = download_lm(h, o.G_th, g_theta))) return rc;
-  if (g_lambda) HIPCHK(h, hipMemcpy(g_lambda, h->par + o.G_la, (size_t)g.L * g.K * 8, hipMemcpyDeviceToHost));
-  if (g_nu) HIPCHK(h, hipMemcpy(g_nu, h->par + o.sc + SC_G_NU, 8, hipMemcpyDeviceToHost));
-  if (g_nu_cache) HIPCHK(h, hipMemcpy(g_nu_cache, h->par + o.sc + SC_G_NU_STALE, 8, hipMemcpyDeviceToHost));
+  if (g_lambda && (rc = d2h(h, g_lambda, h->par + o.G_la, (size_t)g.L * g.K * 8))) return rc;
+  if (g_nu && (rc = d2h(h, g_nu, h->par + o.sc + SC_G_NU, 8))) return rc;
+  if (g_nu_cache && (rc = d2h(h, g_nu_cache, h->par + o.sc + SC_G_NU_STALE, 8))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return VMR_OK;
 }
 
