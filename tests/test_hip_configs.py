@@ -137,19 +137,21 @@ def test_config3_full_size_fit_stops_where_the_oracle_stops():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mode", ["default", "three_levels_two_passes", "tie_by_tie_walk"])
+@pytest.mark.parametrize("mode", ["default", "one_pass_two_levels", "two_passes", "no_lds_levels"])
 def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
-    """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): the statistics H do
-    not fit in LDS beside the rho pass' tables, so the engine either keeps two levels there (default), or rebuilds H in
-    a second pass (VMR_HC=3), and steps denser than the owner map are walked tie by tie (VMR_ECAP=1024 forces it)."""
+    """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): a level of the factor
+    table F or of the statistics H is 24 KB here, so only a few levels of each fit in LDS beside each other.  The engine
+    then either keeps what fits in one pass (the rest is read from / added to global memory) or rebuilds H in a second
+    pass; every shape is held to the oracle, including no LDS level at all."""
     import torch
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
-    if mode == "three_levels_two_passes":
-        monkeypatch.setenv("VMR_HC", "3")
-    elif mode == "tie_by_tie_walk":
-        monkeypatch.setenv("VMR_ECAP", "1024")
+    env = {"one_pass_two_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "2", "VMR_HC": "2"},
+           "two_passes": {"VMR_TWO_PASS": "1", "VMR_YT": "5", "VMR_HC": "5"},
+           "no_lds_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "0", "VMR_HC": "0", "VMR_TPB": "256"}}.get(mode, {})
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     L, N, M, K = 1, 1500, 1000, 3
     net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.5, seed=2, device="cuda:0")
     eng = CaviEngine(net.X, None, K=K, mutuality=True, device=0)

@@ -91,11 +91,16 @@ def test_m4000_mutuality_tables_fill_lds(vmr_format):
     _run(L=1, N=24, M=4000, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2, fmt=vmr_format)     # ~150 KB of LDS tables
 
 
-def test_reporter_tables_beyond_lds_are_refused():
+def test_reporter_tables_beyond_lds_are_refused(monkeypatch):
+    """Dense tiles keep (K + 2) * 8 bytes per reporter in LDS and refuse what does not fit; report lists keep as many
+    table levels as fit and read the rest from global memory, so the same shape is accepted there."""
     from vimure_amd.engine import CaviEngine
     X = np.zeros((1, 4, 4, 7000), np.uint8)
+    monkeypatch.setenv("VMR_FORMAT", "dense")
     with pytest.raises(ValueError, match="LDS"):
         CaviEngine(X, None, K=2, mutuality=True)
+    monkeypatch.setenv("VMR_FORMAT", "sparse")
+    _run(L=1, N=12, M=7000, K=2, eta=0.4, mutuality=True, mask="random", sweeps=2, fmt="sparse")
 
 
 def test_m8300_beyond_the_list_format_uses_dense_tiles(monkeypatch):

@@ -25,6 +25,7 @@
 #include <vector>
 #include <utility>
 #include <algorithm>
+#include <type_traits>
 
 #include "vimure_hip.h"
 
@@ -58,15 +59,15 @@ struct Geo {
   int Gl;       // workgroups per layer for tile-pair kernels
   int Gm;       // workgroups per layer for the mask kernel
   int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
-  int hc;       // how many of them (0..HC_MAX) are accumulated in LDS; the rest goes to global atomics
+  int hc;       // how many of them are accumulated in LDS (dense tiles: 0..HC_MAX); the rest goes to global atomics
+  int yt;       // report lists: levels of the factor table F the rho pass keeps in LDS; the rest is read from global
   int fuse_full; // rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
   int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
   int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
-  int ecap;     // report lists: entries of a 64-tie step whose owners a wave resolves through its LDS map
   int dbg;      // timing experiments only (env VMR_DEBUG; results are wrong): dense path 1 = skip per-report math, 2 = skip
-                // the scan; report lists 8 = no H flush
+                // the scan; report lists 8 = no H flush, 16 = no walk 1, 32 = no walk 2, 64 = no exp in the tie update
   double eps;
 };
 
@@ -87,11 +88,15 @@ struct vmr_ctx {
   // report lists (sparse format, see k_rho_sp); X is freed once they exist
   int sparse = 0;
   unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
-  unsigned* rp = nullptr;      // [L][N*N+1] exclusive scan of the ties' report counts, relative to ebase[l]
-  unsigned* tc = nullptr;      // [L][N*N] mutual reports of the tie | sum of its plain counts << 14
+  unsigned* rs = nullptr;      // [L][N*N/64+1] first entry of every 64-tie step, relative to ebase[l]
+  double* Fg = nullptr;        // [L][Y][Mp][K] per-report factors of the rho update (k_build_f / k_fin_gamma)
+  bool ftab_valid = false;     // Fg matches the current parameters
+  double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
+  int sp_tpb = 256;            // threads per workgroup of k_rho_sp
   unsigned* Qt = nullptr;      // [L][N*N] sum_m R[t,m] X[mirror(t),m]
   unsigned long long* ebase = nullptr;   // device [L]
   unsigned long long nnz = 0;  // non-zero counts in X
+  unsigned long long n_slots = 0;   // entry slots of the report lists: nnz + the padding of the full rounds
   int all_full = 0;            // every mask row is all ones
   // mask lists (partial rows with few reporters), see k_mask_lists
   unsigned* rq = nullptr;              // [L][N*N+1]
@@ -1152,23 +1157,36 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 //
 // X is a tensor of COUNTS of which a few per cent are non-zero; every update touches only those, and the only
 // thing the mutuality terms need besides a report is the mirrored count X[l,j,i,m].  vmr_create therefore turns
-// the dense tensor into one 4-byte entry per non-zero count, tie after tie:
-//     bits 0..12  reporter m          bit 13      R[l,i,j,m]
-//     bits 16..23 count x             bits 24..31 mirror count y = X[l,j,i,m]  (0 when mutuality is off)
-// with rp[l][t] (u32, N*N+1 per layer) = first entry of tie t, relative to the layer's base, rcls[l][t] = the
-// class of the tie's mask row (0 empty, 1 all ones, 2 partial) and Qt[l][t] = sum_m R[t,m] X[mirror(t),m] (the
-// ELBO's mirror sum, a constant of the data).  A sweep then reads 4 B per report + 4 B per tie + rho/log-prior
-// instead of the 1 B per (tie, reporter) of the dense layout, and no tile pair has to be staged: 4.5 GB -> 1.2 GB
-// per sweep at BASELINE config 3.  The dense tensor is freed once the lists exist.
+// the dense tensor into one 4-byte entry per non-zero count:
+//     bits 0..18  y * Mp + m  (mirror count y = X[l,j,i,m], 0 when mutuality is off; reporter m): the index of the
+//                 report's row in the per-(y, m) tables F and H
+//     bit 19      R[l,i,j,m]      bits 20..25  the tie's place in its step      bits 26..31  count x
+// (counts above 63 keep the dense tiles).  Ties are taken in STEPS of 64 consecutive ties -- what one wave of k_rho_sp
+// handles at a time, one tie per lane.  The entries of a step are stored in two parts (sliced-ELLPACK + a remainder):
+//   rounds   R_s full ROUNDS of 64 slots: slot `lane` of round r holds the r-th report of the step's tie `lane`, or 0
+//            when that tie has fewer.  A lane walks its own tie: sums stay in registers, no scatter.  R_s is the
+//            largest r for which at least half of the ties still have an r-th report (padding <= the slots it saves).
+//   rest     the reports beyond round R_s, round-major (every tie's next report, ties ascending), each naming its
+//            tie: walked entry-parallel, scattered into the ties' sums with LDS adds.  A trip of 64 consecutive
+//            entries holds (up to) 64 different consecutive ties -- consecutive LDS addresses, no collisions --
+//            until only the step's most reported tie is left (single-tie trips: wave reduction, one add).
+// rs[l][2s] / rs[l][2s+1] (u32) = first slot of step s / of its rest, relative to the layer's base; rcls[l][t] =
+// class of the tie's mask row (0 empty, 1 all ones, 2 partial; not read when every row is all ones), Qt[l][t] =
+// sum_m R[t,m] X[mirror(t),m] (the ELBO's mirror sum, a constant of the data).  A sweep reads 4 B per report (plus
+// the padding) + rho/log-prior instead of 1 B per (tie, reporter).  The dense tensor is freed once the lists exist.
 // ==========================================================================================
 #ifndef SP_PF
-#define SP_PF 4
+#define SP_PF 3
 #endif
-// SP_PF: entries per lane that are prefetched one step ahead (the first SP_PF*64 of a step)
-#define ENT_M(e) ((int)((e) & 0x1fffu))
-#define ENT_INR(e) (((e) >> 13) & 1u)
-#define ENT_X(e) (((e) >> 16) & 0xffu)
-#define ENT_Y(e) ((e) >> 24)
+// SP_PF: slots per lane that are prefetched one step ahead (the first SP_PF*64 of a step)
+#define ENT_YM(e) ((e) & 0x7ffffu)
+#define ENT_INR(e) (((e) >> 19) & 1u)
+#define ENT_OW(e) ((int)(((e) >> 20) & 63u))
+#define ENT_X(e) ((e) >> 26)
+#define ENT_CMAX 63u   // largest count an entry holds
+#ifndef ELL_MIN_FILL
+#define ELL_MIN_FILL 32   // a round is stored in full while at least this many of the step's 64 ties reach it
+#endif
 
 __device__ __forceinline__ unsigned nz_bytes(uint4 v) {
   const unsigned M = 0x7f7f7f7fu;
@@ -1177,56 +1195,21 @@ __device__ __forceinline__ unsigned nz_bytes(uint4 v) {
   return __popc(t0) + __popc(t1) + __popc(t2) + __popc(t3);
 }
 
-// per-byte mask: 0xff where the byte of w is non-zero
-__device__ __forceinline__ unsigned nz_mask(unsigned w) {
-  const unsigned M = 0x7f7f7f7fu;
-  const unsigned t = ((((w & M) + M) | w) >> 7) & 0x01010101u;
-  return t * 0xffu;
-}
-__device__ __forceinline__ unsigned byte_sum(unsigned w) {
-  return (w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24);
-}
-#define TC_N1(v) ((v) & 0x3fffu)   // reports of the tie whose mirror count is non-zero ("mutual" class)
-#define TC_X0(v) ((v) >> 14)       // sum of the counts of the other ("plain") reports
-
-// Per tie of one layer (16 lanes per row): rp[t] = non-zero counts n; tc[t] = n1 | X0 << 14, n1 = reports with a
-// non-zero mirror count, X0 = sum of the counts of the plain reports.  A tie whose X0 does not fit 18 bits keeps all
-// its reports in the mutual class (n1 = n, X0 = 0).  The layer total goes to *nnz.
-template <bool MUT>
+// Per tie of one layer (16 lanes per row): rp[t] = its non-zero counts.  The layer total goes to *nnz.
 __global__ __launch_bounds__(256) void k_sp_count(const uint8_t* __restrict__ Xl, unsigned* __restrict__ rpl,
-                                                  unsigned* __restrict__ tcl, unsigned long long* nnz, Geo g) {
+                                                  unsigned long long* nnz, Geo g) {
   __shared__ double red[8];
   const int gl = threadIdx.x & 15;
   unsigned long long mine = 0;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
-    unsigned c = 0, c1 = 0, x0 = 0;
+    unsigned c = 0;
     if (t < T) {
-      const size_t i = t / g.N, j = t - i * g.N, tm = j * g.N + i;
       const uint8_t* row = Xl + t * g.Mp;
-      const uint8_t* mrow = Xl + tm * g.Mp;
-      for (int ch = gl; ch < g.nchunk; ch += 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(row + ch * 16);
-        if (!(v.x | v.y | v.z | v.w)) continue;
-        uint4 y = make_uint4(0, 0, 0, 0);
-        if (MUT) y = *reinterpret_cast<const uint4*>(mrow + ch * 16);
-        const unsigned xs[4] = {v.x, v.y, v.z, v.w}, ys[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned mx = nz_mask(xs[u]), my = nz_mask(ys[u]);
-          c += __popc(mx) >> 3;
-          c1 += __popc(mx & my) >> 3;
-          x0 += byte_sum(xs[u] & ~my);
-        }
-      }
+      for (int ch = gl; ch < g.nchunk; ch += 16) c += nz_bytes(*reinterpret_cast<const uint4*>(row + ch * 16));
     }
-    c = group_sum_u(c, 16); c1 = group_sum_u(c1, 16); x0 = group_sum_u(x0, 16);
-    if (gl == 0 && t < T) {
-      if (x0 >= (1u << 18)) { c1 = c; x0 = 0; }
-      rpl[t] = c;
-      tcl[t] = c1 | (x0 << 14);
-      mine += c;
-    }
+    c = group_sum_u(c, 16);
+    if (gl == 0 && t < T) { rpl[t] = c; mine += c; }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) rpl[T] = 0u;
   // block total (exact in double: < 2^53)
@@ -1279,16 +1262,63 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned* a, const unsigned* _
 #pragma unroll
   for (int u = 0; u < 8; ++u) if (base + u < n) a[base + u] += add;
 }
+// Per step (one wave each): the number of full rounds R_s and the size of the rest; sz[2s] = 64 R_s, sz[2s+1] = rest
+// (exclusive scan of sz = the slot offsets rs).  rpl holds the per-tie counts (not yet scanned).
+__global__ __launch_bounds__(256) void k_sp_plan(const unsigned* __restrict__ rpl, unsigned* __restrict__ sz, Geo g) {
+  const int lane = threadIdx.x & 63;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
+  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
+    const size_t t = s * 64 + lane;
+    const unsigned n = t < T ? rpl[t] : 0u;
+    // R = largest r with |{ties: n >= r}| >= ELL_MIN_FILL  (binary search; the count is non-increasing in r)
+    unsigned lo = 0, hi = (unsigned)g.M;
+    while (lo < hi) {
+      const unsigned mid = (lo + hi + 1) >> 1;
+      if (__popcll(__ballot(n >= mid)) >= ELL_MIN_FILL) lo = mid; else hi = mid - 1;
+    }
+    const unsigned R = lo;
+    unsigned rest = n > R ? n - R : 0u;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) rest += (unsigned)__shfl_xor((int)rest, o2, 64);
+    if (lane == 0) { sz[2 * s] = 64u * R; sz[2 * s + 1] = rest; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sz[2 * NS] = 0u;
+}
 
-// Write the entries of one layer (16 lanes per tie) and the mirror sums Qt.  Ties are grouped in steps of 64
-// consecutive ties (what one wave of k_rho_sp takes at a time); inside a step the PLAIN reports (mirror count 0) of
-// its ties come first, tie after tie, then the MUTUAL ones (tie after tie): the rho pass walks the two classes with
-// different arithmetic and wants each 64-entry trip to hold one class.  rpl is the exclusive scan of the per-tie
-// totals, so a step starts at rpl[64 s] and the class runs of a tie follow from the counts of the ties before it.
+// Place the entries of one layer: k_sp_fill wrote them tie-major (tie t's entries at rpl[t], reporters ascending; rpl
+// = exclusive scan of the per-tie counts); this kernel (one wave per step) moves them into the step's rounds and rest.
+__global__ __launch_bounds__(256) void k_sp_round(const unsigned* __restrict__ rpl, const unsigned* __restrict__ rsl,
+                                                  const unsigned* __restrict__ Ein, unsigned* __restrict__ Eout, Geo g) {
+  const int lane = threadIdx.x & 63;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
+  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
+    const size_t t = s * 64 + lane;
+    const bool ok = t < T;
+    const unsigned r0 = rpl[ok ? t : T], n = rpl[ok ? t + 1 : T] - r0;
+    const unsigned ea = rsl[2 * s], et = rsl[2 * s + 1];
+    const unsigned R = (et - ea) >> 6;
+    for (unsigned r = 0; r < R; ++r) Eout[(size_t)ea + r * 64 + lane] = n > r ? Ein[(size_t)r0 + r] : 0u;
+    unsigned nmax = n;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, o2, 64));
+    unsigned base = 0;
+    for (unsigned r = R; r < nmax; ++r) {
+      const uint64_t bal = __ballot(n > r);
+      if (n > r) {
+        const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        Eout[(size_t)et + pos] = Ein[(size_t)r0 + r];
+      }
+      base += (unsigned)__popcll(bal);
+    }
+  }
+}
+
+// Write the entries of one layer (16 lanes per tie) and the mirror sums Qt.  rpl is the exclusive scan of the
+// per-tie counts: tie t's entries start at rpl[t], reporters ascending.
 template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
-                                                 const unsigned* __restrict__ rpl, const unsigned* __restrict__ tcl,
-                                                 unsigned* __restrict__ El, unsigned* __restrict__ Qtl, Geo g) {
+                                                 const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
+                                                 unsigned* __restrict__ Qtl, Geo g) {
   const int gl = threadIdx.x & 15;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
@@ -1299,22 +1329,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
     const uint8_t* mrow = Xl + tm * g.Mp;
     const uint64_t* rr = Rl + tc * g.W;
     const uint64_t* rmr = Rl + tm * g.W;
-    // where this tie's two runs start: plain reports of the step's earlier ties, all plain reports of the step
-    const size_t s0 = tc & ~(size_t)63;
-    const int pos_in_step = (int)(tc - s0);
-    unsigned before0 = 0, before1 = 0, tot0 = 0;
-    for (int u = gl; u < 64; u += 16) {
-      const size_t tt = s0 + u;
-      if (tt < T) {
-        const unsigned n_ = rpl[tt + 1] - rpl[tt], n1_ = TC_N1(tcl[tt]);
-        tot0 += n_ - n1_;
-        if (u < pos_in_step) { before0 += n_ - n1_; before1 += n1_; }
-      }
-    }
-    before0 = group_sum_u(before0, 16); before1 = group_sum_u(before1, 16); tot0 = group_sum_u(tot0, 16);
-    const unsigned n_all = rpl[tc + 1] - rpl[tc], n1_all = TC_N1(tcl[tc]);
-    const bool all_mutual = n1_all == n_all;   // (also the ties whose X0 did not fit)
-    size_t pos0 = (size_t)rpl[s0] + before0, pos1 = (size_t)rpl[s0] + tot0 + before1;
+    const unsigned own = (unsigned)(tc & 63) << 20;
+    size_t pos = rpl[tc];
     unsigned q = 0;
     for (int c0 = 0; c0 < g.nchunk; c0 += 16) {   // uniform over the 16 lanes
       const int ch = c0 + gl;
@@ -1324,23 +1340,15 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
         if (MUT) yv = *reinterpret_cast<const uint4*>(mrow + ch * 16);
       }
       const unsigned xs[4] = {v.x, v.y, v.z, v.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
-      unsigned n = 0, n1 = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned mx = nz_mask(xs[u]), my = nz_mask(ys[u]);
-        n += __popc(mx) >> 3;
-        n1 += __popc(mx & my) >> 3;
-      }
-      if (all_mutual) n1 = n;
-      const unsigned n0 = n - n1;
-      unsigned incl0 = n0, incl1 = n1;
+      const unsigned n = nz_bytes(v);
+      unsigned incl = n;
 #pragma unroll
       for (int o2 = 1; o2 < 16; o2 <<= 1) {
-        const unsigned up0 = __shfl_up(incl0, o2, 16), up1 = __shfl_up(incl1, o2, 16);
-        if (gl >= o2) { incl0 += up0; incl1 += up1; }
+        const unsigned up = __shfl_up(incl, o2, 16);
+        if (gl >= o2) incl += up;
       }
-      const unsigned t0_ = __shfl(incl0, 15, 16), t1_ = __shfl(incl1, 15, 16);
-      size_t w0 = pos0 + incl0 - n0, w1 = pos1 + incl1 - n1;
+      const unsigned tot = __shfl(incl, 15, 16);
+      size_t w = pos + incl - n;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         unsigned dw = xs[u];
@@ -1355,12 +1363,10 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
             y = (ys[u] >> sh) & 0xffu;
             if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
           }
-          const unsigned ent = (unsigned)m | (inr << 13) | (x << 16) | (y << 24);
-          if (y != 0 || all_mutual) El[w1++] = ent; else El[w0++] = ent;
+          El[w++] = (y * (unsigned)g.Mp + (unsigned)m) | (inr << 19) | own | (x << 26);
         }
       }
-      pos0 += t0_;
-      pos1 += t1_;
+      pos += tot;
     }
     q = group_sum_u(q, 16);
     if (ok && gl == 0) Qtl[tm] = q;   // every tie is the mirror of exactly one tie
@@ -1444,108 +1450,168 @@ __global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__
 }
 
 struct SpArgs {
-  const unsigned* E; const unsigned* rp; const unsigned* tc; const unsigned long long* ebase; const uint64_t* Rb;
-  const uint8_t* rcls;
+  const unsigned* E; const unsigned* rs; const unsigned long long* ebase; const uint64_t* Rb; const uint8_t* rcls;
   double* rho; const double* logpr; const double* par; double* slotR; const double* lutg; double* Hg; double* slotF;
   const unsigned* Qt;
   const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask lists (null: read the mask words)
-  int Gl, all_full, do_hist;
+  const double* Fg;   // per-report factors F[l][y][m][k], see k_build_f
+  int Gl, all_full;
+  int do_hist;        // 1: accumulate the statistics H; 2: "count mode" (vmr_create): rho = (0, 1, 0, ..) for every tie, slot 1 gets sum x
+  int yt, hc;         // levels (mirror counts 0..) of F / of the statistics H held in LDS
 };
+
+// Per-report factor of the rho update, a function of (reporter m, mirror count y, category k) only:
+//   F[l][y][m][k] = (E[log theta_lm] + E[log lambda_lk]) * w1_k(m, y),   w1 = z1 / (z1 + z2), den == 0 -> 1   (model.py:685-693, 911-921)
+// so a report contributes x * F to its tie's U_k: one table read and K multiplies instead of a reciprocal per report.
+// Built once per sweep for all levels (a few KB..MB, L2-resident); the rho pass keeps the populous low levels in LDS.
+__device__ __forceinline__ double f_entry(int mut, double lth, double gth, double lla, double gla, double gnu, int y) {
+  return (lth + lla) * (mut ? w1_of(gth * gla, gnu * (double)y) : 1.0);   // mutuality off: data_z1 = x (model.py:680)
+}
+__global__ __launch_bounds__(256) void k_build_f(const double* __restrict__ par, double* __restrict__ Fg, Geo g) {
+  const ParOff o = par_off(g.L, g.Mp, g.K);
+  const int l = blockIdx.x, K = g.K;
+  const double gnu = par[o.sc + SC_G_NU];
+  double* Fl = Fg + (size_t)l * g.Y * g.Mp * K;
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < g.Y * g.Mp; it += gridDim.y * blockDim.x) {
+    const int y = it / g.Mp, m = it - y * g.Mp;
+    const double lth = par[o.l_th + (size_t)l * g.Mp + m], gth = par[o.G_th + (size_t)l * g.Mp + m];
+    for (int k = 0; k < K; ++k)
+      Fl[(size_t)it * K + k] = (m < g.M) ? f_entry(g.mut, lth, gth, par[o.l_la + l * K + k], par[o.G_la + l * K + k], gnu, y) : 0.0;
+  }
+}
+
+// Orders a wave's LDS traffic across lanes.  The LDS executes one wave's operations in issue order (a ds_read issued
+// after another lane's ds_add to the same address sees it), so all that is needed is that the COMPILER keeps them in
+// program order.  A __builtin_amdgcn_fence here -- even at wavefront scope -- also emits s_waitcnt vmcnt(0), which
+// drains the next step's prefetched global loads at every call and serialises memory latency with the walks.
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// block-wide sum for any block size (<= 1024 threads); result valid in thread 0.  `red` = 16 doubles of LDS.
+__device__ __forceinline__ double block_sum_n(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) r += red[w];
+  }
+  return r;
+}
+
+// log(x) for positive normal x (what the ELBO terms feed it: x >= eps), < 1 ulp: the classic reduction x = 2^k m,
+// m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-14 even
+// minimax R of FreeBSD msun's e_log.c (coefficients Lg1..Lg7 are that algorithm's published constants).  About 40 VALU
+// instructions against ~100 of the library's log(), which also serves zero, subnormal, negative and infinite arguments;
+// NaN propagates.  One evaluation per report on ELBO sweeps.
+__device__ __forceinline__ double log_pos(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  k = lo ? k - 1 : k;
+  const double f = m - 1.0, dk = (double)k;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+// K consecutive doubles of a [.][K] array: 16-byte accesses when K is even (the arrays are 256-byte aligned)
+template <int K>
+__device__ __forceinline__ void load_k(const double* __restrict__ p, double (&v)[K]) {
+  if (K % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(p + k);
+      v[k] = t.x; v[k + 1 < K ? k + 1 : k] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = p[k];
+  }
+}
+template <int K>
+__device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v)[K]) {
+  if (K % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k += 2) *reinterpret_cast<double2*>(p + k) = make_double2(v[k], v[k + 1 < K ? k + 1 : k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[k] = v[k];
+  }
+}
 
 // rho update (UPDATE), ELBO data terms (ELBO) and the statistics H (a.do_hist) from the report lists.
 // A WAVE takes 64 consecutive ties per step, one per lane for the per-tie work (log prior, mask sum T, exp /
 // normalise, write-back); their entries are one contiguous run of the list and are walked entry-parallel
-// (coalesced 4-byte loads, lane <-> entry); owner[] maps an entry to its tie (filled by the tie's lane; long runs
-// by the whole wave).  Walk 1 gathers U_k per tie with LDS atomics, walk 2 (after the per-tie update) adds
-// x * rho_new into H and collects the ELBO's log terms.  The waves of a workgroup share only the read-only tables
-// and the LDS levels of H, so the step loop has no workgroup barrier: waves drift apart and cover each other's
-// memory latency; the next step's values and entries are prefetched into registers.
-// Inclusive prefix sum over the 64 lanes of a wave with DPP adds only (no LDS traffic): shifts inside the 16-lane
-// rows, then the row totals are broadcast to the rows after them.
-__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-  return x;
-}
-
-// Orders a wave's LDS traffic across lanes: the LDS executes one wave's operations in issue order, so all that is
-// needed is that the compiler keeps them in program order.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-
-#ifndef SP_LB
-#define SP_LB 1
+// (coalesced 4-byte loads, lane <-> entry; an entry names its tie's lane).  Walk 1 gathers U_k = sum x F[y][m][k] per
+// tie with LDS atomics into the wave's own sums, walk 2 (after the per-tie update) adds x * rho_new into H and collects
+// the ELBO's log terms.  The waves of a workgroup (up to 16) share only the read-only tables and the LDS levels of H,
+// so the step loop has no workgroup barrier: waves drift apart and cover each other's latency; the next step's
+// per-tie values and first entries are prefetched into registers.
+#ifndef SP_TPB_MAX
+#define SP_TPB_MAX 1024
+#endif
+#ifndef SP_WPE
+#define SP_WPE 6   // waves per SIMD the kernel is compiled for (80 VGPRs; forcing 8, i.e. 64 VGPRs, spills: measured slower)
 #endif
 template <int K, bool MUT, bool UPDATE, bool ELBO>
-__global__ __launch_bounds__(TPB, SP_LB) void k_rho_sp(SpArgs a, Geo g) {
+__global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
   extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int Mp = g.Mp;
+  const unsigned ytm = UPDATE ? (unsigned)a.yt * (unsigned)Mp : 0u;    // rows (y, m) of F held in LDS
+  const unsigned hcm = a.do_hist ? (unsigned)a.hc * (unsigned)Mp : 0u; // rows of H held in LDS
   size_t off = 0;
-  // per reporter: E[log theta_m] and, with mutuality, cb_m = G_nu / G_theta_m beside it (one 16-byte LDS read per
-  // mutual report; the weight's c[m,k] = G_nu / (G_theta_m G_lambda_k) = cb_m / G_lambda_k)
-  double* tb = reinterpret_cast<double*>(smem + off); off += (size_t)g.Mp * (MUT ? 16 : 8);
-  double* red = reinterpret_cast<double*>(smem + off); off += 8 * 8;
+  double* F = reinterpret_cast<double*>(smem + off); off += (size_t)ytm * K * 8;             // [yt][Mp][K]
+  const int nHc = (int)hcm * (K - 1);
+  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                 // [K-1][hc][Mp]: categories 1..K-1
+  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)Mp * 8 : 0;
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
-  const int nHc = a.do_hist ? g.hc * g.Mp * K : 0;
-  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;
-  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)g.Mp * 8 : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // entry slot of a lane within a 64-entry trip: the (usually 2-8) consecutive entries of one tie go to lanes 32 / 16 / 48
-  // apart, i.e. to different LDS service groups, so their adds to the tie's sum do not collide on one address
-  const unsigned pl = ((unsigned)(lane & 15) << 2) | ((unsigned)(lane >> 5) & 1u) | ((((unsigned)lane >> 4) & 1u) << 1);
-  // wave-private: per-tie sums (U of the mutual reports, then the tie's new rho; ELBO variants: exp(rho), and rho in
-  // rt), the plain reports' sum s1 and the owner map
-  double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)TPB * K * 8;
-  double* rt = ELBO ? reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K : ut; off += ELBO ? (size_t)TPB * K * 8 : 0;
-  double* s1 = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64; off += (size_t)TPB * 8;
-  unsigned char* owner = smem + off + (size_t)wv * g.ecap;
-  const unsigned ecap = (unsigned)g.ecap;
+  double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
+  // wave-private, [K][64], for the rest of a step: the ties' sums U, then their new rho (ELBO variants: exp(rho) there and
+  // rho in rt)
+  double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)nw * 64 * K * 8;
+  double* rt = ELBO ? reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K : ut;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);   // steps of 64 ties; a workgroup owns a contiguous range, its waves interleave
   const long long s0 = (long long)gb * NS / a.Gl, s1_ = (long long)(gb + 1) * NS / a.Gl;
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
-  int bad = 0;   // a G_theta or G_lambda that underflowed to 0: its weight is 0 even for a plain report (den == 0 rule)
-  for (int m = tid; m < g.Mp; m += TPB) {
-    const double lt_ = a.par[o.l_th + (size_t)l * g.Mp + m], gt_ = a.par[o.G_th + (size_t)l * g.Mp + m];
-    if (MUT) { tb[2 * m] = lt_; tb[2 * m + 1] = (gt_ == 0.0) ? (double)INFINITY : gnu / gt_; }
-    else tb[m] = lt_;
-    if (ELBO) Gth[m] = gt_;
-    if (MUT && m < g.M && gt_ == 0.0) bad = 1;
-  }
-  for (int q = tid; q < nHc; q += TPB) Hc[q] = 0.0;
+  const double* Fl = a.Fg + (size_t)l * g.Y * Mp * K;
+  for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
+  for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
+  if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
   const double* lut = a.lutg + (size_t)l * g.W * 256;
-  for (int w = tid; w < g.W; w += TPB) {
+  for (int w = tid; w < g.W; w += nthr) {
     double v = 0.0;
     for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
     wsum[w] = v;
   }
-  double Ela[K], lla[K], Gla[K];
+  double Ela[K], Gla[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    Ela[k] = a.par[o.E_la + l * K + k]; lla[k] = a.par[o.l_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k];
-  }
-  double iGla[K];   // 1 / G_lambda_k (inf when it underflowed: the weight is then 0, the reference's den == 0 rule)
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    iGla[k] = (Gla[k] == 0.0) ? (double)INFINITY : 1.0 / Gla[k];
-    if (MUT && Gla[k] == 0.0) bad = 1;
-  }
+  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; }
   const double eps = g.eps;
+  const float rcp_mp = 1.0f / (float)Mp;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
-  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * g.Mp * K;
-  const unsigned* rpl = a.rp + (size_t)l * (T + 1);
-  const unsigned* tcl = a.tc + (size_t)l * T;
+  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
+  const unsigned* rsl = a.rs + (size_t)l * (2 * NS + 1);
   const unsigned* El = a.E + a.ebase[l];
   const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
   const uint8_t* cl = a.rcls + (size_t)l * T;
@@ -1554,130 +1620,146 @@ __global__ __launch_bounds__(TPB, SP_LB) void k_rho_sp(SpArgs a, Geo g) {
   const double* lpl = a.logpr + (size_t)l * T * K;
   const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
   const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
-  const double* Eth = a.par + o.E_th + (size_t)l * g.Mp;
+  const double* Eth = a.par + o.E_th + (size_t)l * Mp;
 
-  // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 entries of
-  // the wave's next step and the entry range of the one after are in flight.
-  unsigned r0n = 0, r1n = 0, clsn = 0, qn = 0, tcn = 0;
+  // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 slots of
+  // the wave's next step and the slot range of the one after are in flight.
+  unsigned clsn = 0, qn = 0;
   double lpn[K], rn[K];
   unsigned pen[SP_PF];
-  unsigned ea1 = 0, eb1 = 0, ea2 = 0, eb2 = 0;
-  auto fetch_range = [&](long long s, unsigned& ea, unsigned& eb) {
-    const size_t t0 = (size_t)s * 64;
-    const size_t t1 = t0 + 64 < T ? t0 + 64 : T;
-    ea = rpl[t0 < T ? t0 : T];
-    eb = rpl[t1];
-  };
-  auto fetch_tie = [&](long long s, unsigned ea, unsigned eb) {
+  unsigned ea1 = 0, et1 = 0, ee1 = 0, ea2 = 0, et2 = 0, ee2 = 0;
+  auto fetch_range = [&](long long s, unsigned& ea, unsigned& et, unsigned& ee) { ea = rsl[2 * s]; et = rsl[2 * s + 1]; ee = rsl[2 * s + 2]; };
+  auto fetch_tie = [&](long long s, unsigned ea, unsigned ee) {
     const size_t t = (size_t)s * 64 + lane;
     const bool ok = t < T;
-    r0n = rpl[ok ? t : T];
-    r1n = rpl[ok ? t + 1 : T];
-    tcn = ok ? tcl[t] : 0u;
     clsn = ok ? (a.all_full ? 1u : (unsigned)cl[t]) : 0u;
     if (ELBO && MUT) qn = ok ? Ql[t] : 0u;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      lpn[k] = ((UPDATE || ELBO) && ok) ? lpl[t * K + k] : 0.0;
-      rn[k] = (!UPDATE && ok) ? rl[t * K + k] : 0.0;
-    }
+    for (int k = 0; k < K; ++k) { lpn[k] = 0.0; rn[k] = 0.0; }
+    if ((UPDATE || ELBO) && ok) load_k<K>(lpl + t * K, lpn);
+    if (!UPDATE && ok && a.do_hist != 2) load_k<K>(rl + t * K, rn);
 #pragma unroll
     for (int j = 0; j < SP_PF; ++j) {
-      const unsigned q = pl + (unsigned)j * 64;
+      const unsigned q = (unsigned)lane + (unsigned)j * 64;
       unsigned v = 0u;
-      if (q < eb - ea) v = El[(size_t)ea + q];
+      if (q < ee - ea) v = El[(size_t)ea + q];
       pen[j] = v;
     }
   };
   const long long sfirst = s0 + wv;
   if (sfirst < s1_) {
-    fetch_range(sfirst, ea1, eb1);
-    if (sfirst + TPB / 64 < s1_) fetch_range(sfirst + TPB / 64, ea2, eb2);
-    fetch_tie(sfirst, ea1, eb1);
+    fetch_range(sfirst, ea1, et1, ee1);
+    if (sfirst + nw < s1_) fetch_range(sfirst + nw, ea2, et2, ee2);
+    fetch_tie(sfirst, ea1, ee1);
   }
-  // plain reports take the short path only when no weight of the launch is forced to 0
-  const bool simple_ok = __syncthreads_or(bad) == 0;   // (also the barrier after the tables)
+  __syncthreads();   // tables
   double Tfull = 0.0;
   for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
 
-  // per-report arithmetic
-  auto plain_val = [&](unsigned ent) -> double {   // x E[log theta_m]; the E[log lambda_k] x part is X0, a constant of the tie
-    const int m = ENT_M(ent);
-    return (double)ENT_X(ent) * tb[MUT ? 2 * m : m];
-  };
-  auto mutual_vals = [&](unsigned ent, double (&U)[K]) {   // (E log theta_m + E log lambda_k) x w1_k(m, y)
-    const int m = ENT_M(ent);
-    const double dx = (double)ENT_X(ent);
-    if (MUT) {
-      const double2 te = *reinterpret_cast<const double2*>(tb + 2 * m);
-      double w[K];
-      weights_cb<K>(w, te.y, iGla, ENT_Y(ent));
+  // the K factors of a report's (y, m) row: LDS copy of the populous levels, the global table beyond
+  // (NEAR: every level is in LDS -- decided once per launch, so the walks carry no per-trip test for the other case)
+  const bool all_near = (!UPDATE || a.yt >= g.Y) && (!a.do_hist || a.hc >= g.Y);
+  auto f_row = [&](unsigned ym, double (&f)[K], auto near) {
+    if (decltype(near)::value) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) U[k] = (te.x + lla[k]) * (dx * w[k]);
-    } else {
-      const double lt = tb[m];
-#pragma unroll
-      for (int k = 0; k < K; ++k) U[k] = (lt + lla[k]) * dx;
+      for (int k = 0; k < K; ++k) f[k] = F[ym * K + k];
+      return;
     }
-  };
-  auto stats_elbo = [&](unsigned ent, int ow, const double* rt_, const double* ut_) {   // walk 2, one report of tie ow
-    const int m = ENT_M(ent);
-    const unsigned y = ENT_Y(ent);
-    const double dx = (double)ENT_X(ent);
-    if (a.do_hist) hist_add<K>(Hc, Hl, g.Mp, m, y, dx, rt_ + ow * K, (unsigned)g.hc);
-    if (ELBO) {
-      double inner = 0.0;
-      if (ENT_INR(ent)) {
-        const double z2 = gnu * (double)y, gt = Gth[m];
-        const double* er = ut_ + ow * K;
+    const bool far = ym >= ytm;
+    const unsigned il = (far ? 0u : ym) * K;
 #pragma unroll
-        for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+    for (int k = 0; k < K; ++k) f[k] = F[il + k];
+    if (__any(far)) {
+      if (far) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) f[k] = Fl[(size_t)ym * K + k];
+        // wait for it HERE: f[] would otherwise carry a pending global load past the join, and the compiler, unable to
+        // count it there, would drain every outstanding load (the next step's prefetch) with vmcnt(0) in ALL trips
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        asm volatile("" ::: "memory");   // keeps the two address spaces apart (no select of pointers -> flat loads)
       }
-      e_log += dx * log(inner + eps);
     }
+  };
+  // one report into H: categories 1..K-1 only -- sum_k rho_k = 1, so H_0 = (sum of x, a constant of the data) - sum_{k>0} H_k
+  // is rebuilt when the copies of H are folded (h_fold_item).  Slot 0 (global only) collects x * (1 - sum_k rho_k) of the ties
+  // whose rho does not sum to 1 (an all-zero row after underflow, model.py:808-811; rows of a user-supplied prior): dfc.
+  auto h_add = [&](unsigned ym, const double (&xr)[K], double xd, bool on, auto near) {
+    if (on) {
+      if (decltype(near)::value || ym < hcm) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], xr[k]);
+      } else {   // a level beyond the LDS copy (rare)
+        double* d = Hl + (size_t)ym * K;
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&d[k], xr[k]);
+        asm volatile("" ::: "memory");   // (as above: no flat atomics)
+      }
+      if (xd != 0.0) atomicAdd(&Hl[(size_t)ym * K], xd);
+    }
+  };
+  auto elbo_log = [&](unsigned ent, unsigned ym, double dx, const double (&er)[K]) {   // x log(sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps)
+    unsigned y = (unsigned)((float)ym * rcp_mp);
+    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const unsigned m = ym - y * (unsigned)Mp;
+    double inner = 0.0;
+    if (ENT_INR(ent)) {
+      const double z2 = gnu * (double)y, gt = Gth[m];
+#pragma unroll
+      for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+    }
+    e_log += dx * log_pos(inner + eps);
   };
 
-  for (long long s = sfirst; s < s1_; s += TPB / 64) {
+  for (long long s = sfirst; s < s1_; s += nw) {
     const size_t t = (size_t)s * 64 + lane;
     const bool act = t < T;
-    const unsigned r0 = r0n, r1 = r1n, cls = clsn, qt = qn, tcv = tcn;
-    const unsigned ea = ea1, ne = eb1 - ea1;
+    const unsigned cls = clsn, qt = qn;
+    const unsigned ea = ea1, nt = ee1 - ea1;          // the step's slots: full rounds, then the rest
+    const int R = (int)((et1 - ea1) >> 6);            // full rounds (trips in which lane <-> tie)
+    const int trips = (int)((nt + 63) >> 6);
+    const bool has_rest = ee1 > et1;
     double lp[K], r[K];
     unsigned pe[SP_PF];
 #pragma unroll
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
 #pragma unroll
     for (int j = 0; j < SP_PF; ++j) pe[j] = pen[j];
+    if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (UPDATE) ut[lane * K + k] = 0.0;
-      else { rt[lane * K + k] = r[k]; if (ELBO) ut[lane * K + k] = exp(r[k]); }
+      for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
     }
-    if (UPDATE) s1[lane] = 0.0;
-    // the two runs of this lane's tie inside the step: plain reports first (all ties), then the mutual ones
-    const unsigned n_t = r1 - r0, n1_t = TC_N1(tcv);
-    const unsigned n0_t = n_t - n1_t;
-    const unsigned i0 = wave_incl_scan_u32(n0_t), i1 = wave_incl_scan_u32(n1_t);
-    const unsigned tot0 = __builtin_amdgcn_readlane((int)i0, 63);
-    const unsigned st0 = i0 - n0_t, st1 = tot0 + i1 - n1_t;   // run starts, relative to the step's first entry
-    // owner[]: the tie (lane) of every entry; a tie's lane fills its runs, long runs are filled by the whole wave
-    auto fill_run = [&](unsigned start, unsigned n) {
-      if (n <= 16u) for (unsigned q = 0; q < n; ++q) owner[start + q] = (unsigned char)lane;
-      uint64_t hm = __ballot(n > 16u);
-      while (hm) {
-        const int hl = __builtin_ctzll(hm);
-        hm &= hm - 1;
-        const unsigned s_h = __builtin_amdgcn_readlane((int)start, hl), n_h = __builtin_amdgcn_readlane((int)n, hl);
-        for (unsigned q = lane; q < n_h; q += 64) owner[s_h + q] = (unsigned char)hl;
+    double dfc = 0.0;   // 1 - sum_k rho_k of this lane's tie, 0 when that is rounding
+    bool irr = false;   // (wave-uniform) some tie of the step has a non-zero dfc
+    double er[K];       // exp(rho) of this lane's tie (ELBO, model.py:971)
+    auto put_rho = [&](bool exact_one) {   // the tie's rho for walk 2
+      if (!exact_one) {
+        double sm = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sm += r[k];
+        dfc = 1.0 - sm;
+        if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;   // rounding of the normalisation
+        irr = a.do_hist && __any(dfc != 0.0);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (ELBO) er[k] = exp(r[k]);
+        if (has_rest) {   // the rest's reports look their tie up in LDS: slot 0 = dfc, categories 1.. as they are
+          rt[k * 64 + lane] = (k == 0) ? dfc : r[k];
+          if (ELBO) ut[k * 64 + lane] = er[k];
+        }
       }
     };
-    const bool fast = ne <= ecap;   // the step's entries fit the owner map (sized from the data's density)
-    if (fast) { fill_run(st0, n0_t); fill_run(st1, n1_t); }
+    if (UPDATE) {
+      if (has_rest) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) ut[k * 64 + lane] = 0.0;
+      }
+    } else put_rho(false);
     // next steps' loads
-    ea1 = ea2; eb1 = eb2;
-    if (s + TPB / 64 < s1_) {
-      if (s + 2 * (TPB / 64) < s1_) fetch_range(s + 2 * (TPB / 64), ea2, eb2);
-      fetch_tie(s + TPB / 64, ea1, eb1);
+    ea1 = ea2; et1 = et2; ee1 = ee2;
+    if (s + nw < s1_) {
+      if (s + 2 * nw < s1_) fetch_range(s + 2 * nw, ea2, et2, ee2);
+      fetch_tie(s + nw, ea1, ee1);
     }
     double Tt = 0.0;
     bool rowfull = false;
@@ -1697,168 +1779,166 @@ __global__ __launch_bounds__(TPB, SP_LB) void k_rho_sp(SpArgs a, Geo g) {
     }
     wave_sync();   // everything below is wave-local: LDS operations of a wave complete in order
 
-    auto update_tie = [&]() {   // per-tie update from the finished sums
-      const double x0 = simple_ok ? (double)TC_X0(tcv) : 0.0, sp = simple_ok ? s1[lane] : 0.0;
-      double sum = 0.0;
+    if (UPDATE) {
+      // walk 1: U_k of every tie = sum x F[y][m][k].  Full rounds: this lane's own tie, in registers; the rest: LDS adds.
+      double U[K];
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const double u = ut[lane * K + k] + (sp + lla[k] * x0);
-        r[k] = exp((lp[k] + u) - Tt * Ela[k]);   // no max-subtraction, as model.py:807
-        sum += r[k];
-      }
-      if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
+      for (int k = 0; k < K; ++k) U[k] = 0.0;
+      auto trip1 = [&](unsigned ent, int j, auto near) {
+        double f[K];
+        f_row(ENT_YM(ent), f, near);
+        const double dx = (double)ENT_X(ent);   // (an empty slot has x = 0)
+        if (j < R) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) r[k] /= sum;
-      }
+          for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
+        } else {
+          const bool v = (unsigned)lane + (unsigned)j * 64 < nt;
+          const int ow = ENT_OW(ent);
+          const int o0 = __builtin_amdgcn_readfirstlane(ow);   // (lane 0 of a trip always holds a report)
+          if (__all(ow == o0 || !v)) {   // all of them inside one tie (a tie most reporters report on): reduce, then one add
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (act) { rl[t * K + k] = r[k]; accF[k] += rowfull ? r[k] : 0.0; }
-        if (ELBO) { rt[lane * K + k] = r[k]; ut[lane * K + k] = exp(r[k]); }   // exp(rho), model.py:971 (U is consumed)
-        else ut[lane * K + k] = r[k];                                          // rt aliases ut
+            for (int k = 0; k < K; ++k) {
+              const double sm_ = wave_sum(dx * f[k]);
+              if (lane == 0) atomicAdd(&ut[k * 64 + o0], sm_);
+            }
+          } else if (v) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) atomicAdd(&ut[k * 64 + ow], dx * f[k]);
+          }
+        }
+      };
+      const int trips1 = (g.dbg & 16) ? 0 : trips;   // (timing experiment: no walk 1)
+      auto walk1 = [&](auto near) {
+#pragma unroll
+        for (int j = 0; j < SP_PF; ++j) {
+          if (j < trips1) trip1(pe[j], j, near);   // wave-uniform
+        }
+        if (trips1 > SP_PF) {   // long steps: rolling prefetch one trip ahead
+          unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
+          unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
+          for (int j = SP_PF; j < trips; ++j) {
+            const unsigned cur = nx;
+            q += 64;
+            nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
+            trip1(cur, j, near);
+          }
+        }
+      };
+      if (all_near) walk1(std::true_type{}); else walk1(std::false_type{});
+      if (has_rest) {
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < K; ++k) U[k] += ut[k * 64 + lane];
       }
-    };
-    auto elbo_tie = [&]() {
-      if (!(ELBO && act)) return;
+      // per-tie update from the finished sums
+      double aa[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) aa[k] = (lp[k] + U[k]) - Tt * Ela[k];
+      bool done = false;
+      if (K == 2) {
+        // two categories: rho_0 = 1 / (1 + e^(a1-a0)) -- one exp, one divide -- wherever the reference's raw
+        // exponentials neither overflow nor underflow (then equal to exp(a_k) / sum up to rounding); other ties below
+        const double d = aa[1] - aa[0];
+        const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
+        if (__all(safe)) {
+          const double e = (g.dbg & 64) ? d : exp(d);   // (timing experiment: no exp)
+          r[0] = 1.0 / (1.0 + e);
+          r[1] = e * r[0];
+          done = true;
+        }
+      }
+      if (!done) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { r[k] = exp(aa[k]); sum += r[k]; }   // no max-subtraction, as model.py:807
+        if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] /= sum;
+        }
+      }
+      if (act) {
+        store_k<K>(rl + t * K, r);
+#pragma unroll
+        for (int k = 0; k < K; ++k) accF[k] += rowfull ? r[k] : 0.0;
+      }
+      if (has_rest) wave_sync();   // (U of the rest is consumed; without the ELBO rt aliases ut)
+      put_rho(done);
+      if (has_rest) wave_sync();
+    }
+    if ((a.do_hist || ELBO) && !(g.dbg & 32)) {   // walk 2: H of the (new) rho; ELBO log terms   (dbg 32: timing experiment without it)
+      auto trip2 = [&](unsigned ent, int j, auto near) {
+        const unsigned ym = ENT_YM(ent);
+        const double dx = (double)ENT_X(ent);
+        double xr[K];
+        if (j < R) {   // this lane's own tie
+#pragma unroll
+          for (int k = 1; k < K; ++k) xr[k] = dx * r[k];
+          if (a.do_hist) h_add(ym, xr, irr ? dx * dfc : 0.0, ENT_X(ent) != 0u, near);
+          if (ELBO) elbo_log(ent, ym, dx, er);
+        } else if ((unsigned)lane + (unsigned)j * 64 < nt) {
+          const int ow = ENT_OW(ent);
+#pragma unroll
+          for (int k = 1; k < K; ++k) xr[k] = dx * rt[k * 64 + ow];
+          if (a.do_hist) h_add(ym, xr, irr ? dx * rt[ow] : 0.0, true, near);
+          if (ELBO) {
+            double eo[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) eo[k] = ut[k * 64 + ow];
+            elbo_log(ent, ym, dx, eo);
+          }
+        }
+      };
+      auto walk2 = [&](auto near) {
+#pragma unroll
+        for (int j = 0; j < SP_PF; ++j) {
+          if (j < trips) trip2(pe[j], j, near);
+        }
+        if (trips > SP_PF) {
+          unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
+          unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
+          for (int j = SP_PF; j < trips; ++j) {
+            const unsigned cur = nx;
+            q += 64;
+            nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
+            trip2(cur, j, near);
+          }
+        }
+      };
+      if (all_near) walk2(std::true_type{}); else walk2(std::false_type{});
+    }
+    if (ELBO && act) {
       double sr = 0.0, se = 0.0, en = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         sr += r[k]; se += r[k] * Ela[k];
-        en += r[k] * lp[k] - r[k] * log(r[k] + eps);   // model.py:1306-1313
+        en += r[k] * lp[k] - r[k] * log_pos(r[k] + eps);   // model.py:1306-1313
       }
       e_lin += en - se * Tt;
       if (MUT) e_q += sr * (double)qt;
-    };
-
-    if (fast) {
-      if (UPDATE) {
-        // walk 1: U of every tie.  Trips [0, tot0) hold plain reports (one multiply-add each), the rest mutual ones.
-        auto add_plain = [&](unsigned ent, int ow, bool p) {   // lanes with p: one plain report each
-          const double val = p ? plain_val(ent) : 0.0;
-          const int o0 = __builtin_amdgcn_readlane(ow, (int)__builtin_ctzll(__ballot(p)));
-          if (__all(ow == o0 || !p)) {   // all of them inside one tie: reduce, then one add
-            const double sm_ = wave_sum(val);
-            if (lane == 0) atomicAdd(&s1[o0], sm_);
-          } else if (p) {
-            atomicAdd(&s1[ow], val);
-          }
-        };
-        auto add_mutual = [&](unsigned ent, int ow, bool p) {
-          double U[K];
-          mutual_vals(ent, U);
-          const int o0 = __builtin_amdgcn_readlane(ow, (int)__builtin_ctzll(__ballot(p)));
-          if (__all(ow == o0 || !p)) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const double sm_ = wave_sum(p ? U[k] : 0.0);
-              if (lane == 0) atomicAdd(&ut[o0 * K + k], sm_);
-            }
-          } else if (p) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) atomicAdd(&ut[ow * K + k], U[k]);
-          }
-        };
-        const unsigned nplain = simple_ok ? tot0 : 0u;   // entries [0, nplain) take the short path
-        auto trip = [&](unsigned ent, unsigned qb) {     // qb = first entry of the trip (wave-uniform)
-          const unsigned q = qb + pl;
-          const bool v = q < ne;
-          const int ow = v ? (int)owner[q] : -1;
-          if (qb + 64 <= nplain) add_plain(ent, ow, v);
-          else if (qb >= nplain) add_mutual(ent, ow, v);
-          else {   // the one trip that holds the class boundary
-            add_plain(ent, ow, v && q < nplain);
-            if (__any(v && q >= nplain)) add_mutual(ent, ow, v && q >= nplain);
-          }
-        };
-        const int trips = (int)((ne + 63) / 64);
-#pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          if ((unsigned)j * 64 < ne) trip(pe[j], (unsigned)j * 64);   // wave-uniform
-        }
-        for (int j = SP_PF; j < trips; ++j) {
-          const unsigned q = pl + (unsigned)j * 64;
-          trip(q < ne ? El[(size_t)ea + q] : 0u, (unsigned)j * 64);
-        }
-        wave_sync();
-        update_tie();
-        wave_sync();
-      }
-      if (a.do_hist || ELBO) {   // walk 2: H of the (new) rho; ELBO log terms
-        const int trips = (int)((ne + 63) / 64);
-#pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          const unsigned q = pl + (unsigned)j * 64;
-          if (q < ne) stats_elbo(pe[j], (int)owner[q], rt, ut);
-        }
-        for (int j = SP_PF; j < trips; ++j) {
-          const unsigned q = pl + (unsigned)j * 64;
-          if (q < ne) stats_elbo(El[(size_t)ea + q], (int)owner[q], rt, ut);
-        }
-      }
-      elbo_tie();
-    } else {
-      // more entries than the owner map holds (a step far denser than the data's average): tie after tie, the whole
-      // wave on one tie's runs, sums through wave reductions
-      if (UPDATE) {
-        for (int ta = 0; ta < 64; ++ta) {   // wave-uniform
-          const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)st0, ta), c0 = (unsigned)__builtin_amdgcn_readlane((int)n0_t, ta);
-          const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)st1, ta), c1 = (unsigned)__builtin_amdgcn_readlane((int)n1_t, ta);
-          double sp = 0.0, U[K], Ua[K];
-#pragma unroll
-          for (int k = 0; k < K; ++k) Ua[k] = 0.0;
-          for (unsigned q = lane; q < c0; q += 64) {
-            const unsigned ent = El[(size_t)ea + b0 + q];
-            if (simple_ok) sp += plain_val(ent);
-            else {
-              mutual_vals(ent, U);
-#pragma unroll
-              for (int k = 0; k < K; ++k) Ua[k] += U[k];
-            }
-          }
-          for (unsigned q = lane; q < c1; q += 64) {
-            mutual_vals(El[(size_t)ea + b1 + q], U);
-#pragma unroll
-            for (int k = 0; k < K; ++k) Ua[k] += U[k];
-          }
-          if (c0 + c1) {
-            sp = wave_sum(sp);
-#pragma unroll
-            for (int k = 0; k < K; ++k) Ua[k] = wave_sum(Ua[k]);
-            if (lane == 0) {
-              s1[ta] = sp;
-#pragma unroll
-              for (int k = 0; k < K; ++k) ut[ta * K + k] = Ua[k];
-            }
-          }
-        }
-        wave_sync();
-        update_tie();
-        wave_sync();
-      }
-      if (a.do_hist || ELBO) {
-        for (int ta = 0; ta < 64; ++ta) {
-          const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)st0, ta), c0 = (unsigned)__builtin_amdgcn_readlane((int)n0_t, ta);
-          const unsigned b1 = (unsigned)__builtin_amdgcn_readlane((int)st1, ta), c1 = (unsigned)__builtin_amdgcn_readlane((int)n1_t, ta);
-          for (unsigned q = lane; q < c0; q += 64) stats_elbo(El[(size_t)ea + b0 + q], ta, rt, ut);
-          for (unsigned q = lane; q < c1; q += 64) stats_elbo(El[(size_t)ea + b1 + q], ta, rt, ut);
-        }
-      }
-      elbo_tie();
     }
-    wave_sync();
+    if (has_rest) wave_sync();
   }
   __syncthreads();
-  if (a.do_hist && !(g.dbg & 8)) hist_flush(Hc, Hl, nHc);
+  if (a.do_hist && !(g.dbg & 8)) {   // flush the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
+    for (int q = tid; q < nHc; q += nthr) {
+      const double v = Hc[q];
+      if (v != 0.0) {
+        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
+        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
+      }
+    }
+  }
   if (UPDATE) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      double v = block_sum(accF[k], red);
+      double v = block_sum_n(accF[k], red);
       if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
     }
   }
   if (ELBO) {
-    double v1 = block_sum(e_lin, red);
-    double v2 = block_sum(e_log, red);
-    double v3 = block_sum(e_q, red);
+    double v1 = block_sum_n(e_lin, red);
+    double v2 = block_sum_n(e_log, red);
+    double v3 = block_sum_n(e_q, red);
     if (tid == 0) {
       double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
       atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
@@ -1884,11 +1964,34 @@ __device__ __forceinline__ double h_fold(double* Hl0, size_t copy_stride, size_t
   Hl0[idx] = t;
   return t;
 }
-__global__ __launch_bounds__(TPB) void k_h_reduce(double* Hg, Geo g) {
-  const size_t hcs = (size_t)g.Y * g.Mp * g.K, n = (size_t)g.L * hcs;
+// Fold the K values of one (y, m) item.  Report lists (Cl != null) accumulate categories 1..K-1 and, in slot 0, the
+// deficit sum x (1 - sum_k rho_k) of irregular ties; with Cl[y][m] = sum x over the item's reports (a constant of the
+// data, from the count-mode launch of vmr_create): H_0 = C - deficit - sum_{k>0} H_k.
+__device__ __forceinline__ void h_fold_item(double* Hl0, size_t copy_stride, size_t item, int K, const double* Cl, double* out) {
+  double rest = 0.0;
+  for (int k = K - 1; k >= 0; --k) {
+    double v = h_fold(Hl0, copy_stride, item * K + k);
+    if (k > 0) rest += v;
+    else if (Cl) { v = Cl[item] - v - rest; Hl0[item * K] = v; }
+    out[k] = v;
+  }
+}
+__global__ __launch_bounds__(TPB) void k_h_reduce(double* Hg, const double* Cg, Geo g) {
+  const size_t items = (size_t)g.Y * g.Mp, hcs = items * g.K, n = (size_t)g.L * items;
+  double tmp[KMAX];
   for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < n; q += (size_t)gridDim.x * TPB) {
-    const size_t l = q / hcs, idx = q - l * hcs;
-    h_fold(Hg + l * NH * hcs, hcs, idx);
+    const size_t l = q / items, it = q - l * items;
+    h_fold_item(Hg + l * NH * hcs, hcs, it, g.K, Cg ? Cg + l * items : nullptr, tmp);
+  }
+}
+// count-mode result -> the constants C[l][y][m], leaving H zeroed
+__global__ __launch_bounds__(TPB) void k_take_counts(double* Hg, double* Cg, Geo g) {
+  const size_t items = (size_t)g.Y * g.Mp, hcs = items * g.K, n = (size_t)g.L * items;
+  for (size_t q = (size_t)blockIdx.x * TPB + threadIdx.x; q < n; q += (size_t)gridDim.x * TPB) {
+    const size_t l = q / items, it = q - l * items;
+    double* Hl0 = Hg + l * NH * hcs;
+    Cg[q] = h_fold(Hl0, hcs, it * g.K + 1);   // count mode put sum x into category 1
+    Hl0[it * g.K + 1] = 0.0;
   }
 }
 template <bool ZERO>
@@ -1920,12 +2023,13 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
 // finishes gamma.  consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for
 // the rho pass that follows.
 __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, double* slotA, double* slotF,
-                                                       double* lutg, int do_phi, int consume, Geo g) {
+                                                       double* lutg, double* Fg, int do_phi, int consume, Geo g) {
   extern __shared__ double dyn[];   // s1[Mp]: sum_{y,k} w1 H per reporter; gthn[Mp]: the new G_theta
   double* s1 = dyn;
   double* gthn = dyn + g.Mp;
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
+  __shared__ double lla_n[KMAX], gla_n[KMAX];   // the new E[log lambda], G_lambda (for the factor table F)
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
   if (tid < K) {
@@ -1941,7 +2045,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
     ela_old[tid] = par[o.p_shp + l * K + tid] / par[o.p_rte + l * K + tid];
     gla_old[tid] = par[o.G_la + l * K + tid];
   }
-  for (int m = tid; m < g.Mp; m += FIN_TPB) s1[m] = 0.0;
+  for (int m = tid; m < g.Mp; m += FIN_TPB) { s1[m] = 0.0; gthn[m] = 0.0; }
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
   const size_t hcs = (size_t)g.Y * g.Mp * K;
@@ -2004,6 +2108,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
         par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
         double lg = digamma_pos(shp) - log(rte);
         par[o.E_la + l * K + k] = shp / rte; par[o.l_la + l * K + k] = lg; par[o.G_la + l * K + k] = exp(lg);
+        lla_n[k] = lg; gla_n[k] = exp(lg);
       }
     }
   }
@@ -2031,7 +2136,20 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
         par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
         double lg = digamma_pos(shp) - log(rte);
         par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+        lla_n[k] = lg; gla_n[k] = exp(lg);
       }
+    }
+  }
+  // (fused sweep, report lists) the factor table F of the rho pass from the new theta, lambda and the current nu
+  if (do_phi && Fg) {
+    __syncthreads();   // (also makes this workgroup's stores of the new E[log theta] visible to all its threads)
+    double* Fl = Fg + (size_t)l * items * K;
+    const double* lthn = par + o.l_th + (size_t)l * g.Mp;
+    for (int it = tid; it < items; it += FIN_TPB) {
+      const int y = it / g.Mp, m = it - y * g.Mp;
+      const double lt = (m < g.M) ? lthn[m] : 0.0;
+      for (int k = 0; k < K; ++k)
+        Fl[(size_t)it * K + k] = (m < g.M) ? f_entry(g.mut, lt, gthn[m], lla_n[k], gla_n[k], gnu, y) : 0.0;
     }
   }
   const double* Eth = par + o.E_th + (size_t)l * g.Mp;
@@ -2086,7 +2204,7 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 // One workgroup per layer adds its share to fin[0..1] with device-scope atomics; the workgroup that draws the
 // last ticket (fin[2]) finishes the scalars and clears the scratch.
 #define FR_G 16   // workgroups per layer of k_fin_rho
-__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, double* slotR, double* elbo_out,
+__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
                                                  double* fin, int do_nu, int do_elbo, int fold, Geo g) {
   __shared__ double red[8];
   __shared__ int last;
@@ -2103,11 +2221,12 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, double
       const int y = it / g.Mp, m = it - y * g.Mp;
       if (m >= g.M || (y == 0 && !fold)) continue;
       const double gth = par[o.G_th + (size_t)l * g.Mp + m], z2 = gnu * (double)y;
+      double hk[KMAX];
+      if (fold) h_fold_item(Hl, hcs, (size_t)it, g.K, Cg ? Cg + (size_t)l * items : nullptr, hk);
+      else for (int k = 0; k < g.K; ++k) hk[k] = Hl[(size_t)it * g.K + k];
       for (int k = 0; k < g.K; ++k) {
-        const size_t idx = (size_t)it * g.K + k;
-        const double hv = fold ? h_fold(Hl, hcs, idx) : Hl[idx];
         const double z1 = gth * par[o.G_la + l * g.K + k];
-        if (g.mut && y > 0) a0 += (z2 / (z1 + z2)) * hv;
+        if (g.mut && y > 0) a0 += (z2 / (z1 + z2)) * hk[k];
       }
     }
   }
@@ -2197,9 +2316,25 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
   return n + 16;
 }
 
-static size_t shmem_sp(const Geo& g, bool mut, bool elbo, bool hist) {
-  return (size_t)g.Mp * (mut ? 16 : 8) + (elbo ? 2 : 1) * (size_t)TPB * g.K * 8 + (size_t)TPB * 8 + 64 +
-         (size_t)g.W * 8 + (hist ? shmem_hc(g) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)(TPB / 64) * g.ecap;
+// LDS bytes of one k_rho_sp workgroup of tpb threads: F levels, H levels, G_theta (ELBO), per-wave tie sums
+static size_t shmem_sp(const Geo& g, int tpb, int yt, int hc, bool update, bool elbo, bool hist) {
+  const size_t lb = (size_t)g.Mp * g.K * 8;
+  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)g.W * 8 + 128 +
+         (size_t)(tpb / 64) * 64 * g.K * 8 * (elbo ? 2 : 1) + 16;
+}
+#define SP_LDS_MAX (160 * 1024)
+// Launch shape of one k_rho_sp variant: the handle's block size and table levels, shrunk until the workgroup fits
+// in LDS (the ELBO variants carry more per-wave state; levels that do not fit are read from / added to global memory).
+struct SpShape { int tpb, yt, hc; size_t smem; };
+static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
+  const Geo& g = h->g;
+  SpShape s{h->sp_tpb, update ? g.yt : 0, hist ? g.hc : 0, 0};
+  auto bytes = [&]() { return shmem_sp(g, s.tpb, s.yt, s.hc, update, elbo, hist); };
+  while (bytes() > SP_LDS_MAX && s.tpb > 256) s.tpb >>= 1;
+  while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
+  while (bytes() > SP_LDS_MAX && s.tpb > 64) s.tpb >>= 1;
+  s.smem = bytes();
+  return s;
 }
 
 struct Prof {
@@ -2242,13 +2377,13 @@ struct Prof {
 // Opt in to > 48 KB of dynamic LDS and size the (persistent) grid to what is resident at once:
 // workgroups per layer = resident workgroups per CU x CUs / L, never more than tile pairs.
 template <class Kern>
-static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl, long long cap = 0) {
+static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl, long long cap = 0, int tpb = TPB) {
   const void* fn = reinterpret_cast<const void*>(k);
   int per_cu = 0;
   for (auto& e : h->occ) if (e.first == fn) per_cu = e.second;
   if (!per_cu) {
     if (smem > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TPB, smem));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, tpb, smem));
     if (per_cu < 1) per_cu = 1;
     h->occ.push_back({fn, per_cu});
   }
@@ -2266,7 +2401,7 @@ static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo) {
   const int fold = (h->h_valid && !h->h_reduced) ? 1 : 0;
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->slotR, h->elbo_dev,
+    hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->Cg, h->slotR, h->elbo_dev,
                        h->elbo_dev + 4, do_nu, do_elbo, fold, g);
   }
   HIPCHK(h, hipGetLastError());
@@ -2278,10 +2413,20 @@ static int ensure_h_folded(vmr_ctx* h) {
   if (h->h_reduced) return VMR_OK;
   const Geo& g = h->g;
   const size_t n = (size_t)g.L * g.Y * g.Mp * g.K;
-  hipLaunchKernelGGL(k_h_reduce, dim3((unsigned)std::min<size_t>(1024, (n + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, g);
+  hipLaunchKernelGGL(k_h_reduce, dim3((unsigned)std::min<size_t>(1024, (n + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, h->Cg, g);
   HIPCHK(h, hipGetLastError());
   h->h_reduced = true;
   return VMR_OK;
+}
+
+static SpArgs sp_args(const vmr_ctx* h, const SpShape& sh, int do_hist) {
+  return SpArgs{h->E, h->rs, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
+                h->rq, h->Rm, h->rbase, h->Fg, 1, h->all_full, do_hist, sh.yt, sh.hc};
+}
+// steps of 64 ties per layer / waves per workgroup: at least one step per wave
+static long long sp_grid_cap(const Geo& g, int tpb) {
+  const long long NS = ((long long)g.N * g.N + 63) / 64, nw = tpb / 64;
+  return (NS + nw - 1) / nw;
 }
 
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
@@ -2290,13 +2435,11 @@ static int launch_hist(vmr_ctx* h) {
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
-    SpArgs a{h->E, h->rp, h->tc, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-             h->rq, h->Rm, h->rbase, 1, h->all_full, 1};
-    const size_t sm = shmem_sp(g, false, false, true);
-    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;   // at least one 64-tie step per wave
+    const SpShape sh = sp_shape(h, false, false, true);
+    SpArgs a = sp_args(h, sh, 1);
     int rc = VMR_OK;
-    DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sm, &a.Gl, NB))) return rc;
-               hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(TPB), sm, h->stream, a, g));
+    DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc;
+               hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
   } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     HistArgs a{h->X, h->rho, h->Hg, 1};
@@ -2370,7 +2513,8 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
       h->fin_attr = true;
     }
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg,
-                       with_phi ? 1 : 0, consume, g);
+                       h->sparse ? h->Fg : nullptr, with_phi ? 1 : 0, consume, g);
+    h->ftab_valid = h->sparse && with_phi;
     if (consume) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
   }
   HIPCHK(h, hipGetLastError());
@@ -2402,15 +2546,22 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     if (!g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   }
   if (mode != 2) h->h_zero = false;
+  if (h->sparse && mode != 2) {
+    if (!h->ftab_valid) {
+      const int by = std::max(1, std::min(64, (g.Y * g.Mp + 255) / 256));
+      hipLaunchKernelGGL(k_build_f, dim3(g.L, by), dim3(256), 0, h->stream, h->par, h->Fg, g);
+      HIPCHK(h, hipGetLastError());
+    }
+    h->ftab_valid = false;   // the nu update that follows changes the weights
+  }
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
-    SpArgs s{h->E, h->rp, h->tc, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-             h->rq, h->Rm, h->rbase, 1, h->all_full, (mode != 2 && !g.two_pass) ? 1 : 0};
-    const size_t ssm = shmem_sp(g, g.mut != 0, mode != 0, s.do_hist != 0);
-    const long long NB = ((long long)g.N * g.N + TPB - 1) / TPB;
+    const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
+    const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
+    SpArgs s = sp_args(h, sh, do_hist);
 #define LSP(MUT_, UPD_, ELB_)                                                                  \
-  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_>, ssm, &s.Gl, NB))) return rc; \
-             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_>), dim3(g.L * s.Gl), blk, ssm, h->stream, s, g))
+  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_>, sh.smem, &s.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
+             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_>), dim3(g.L * s.Gl), dim3(sh.tpb), sh.smem, h->stream, s, g))
     if (g.mut) {
       if (mode == 0) { LSP(true, true, false); } else if (mode == 1) { LSP(true, true, true); } else { LSP(true, false, true); }
     } else {
@@ -2465,7 +2616,6 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.hc = 0;
   g.two_pass = 0;
   g.fuse_full = 0;
-  g.ecap = 1024;
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
   long long maxgm = (T + 255) / 256; if (gm > maxgm) gm = maxgm; if (gm < 1) gm = 1;
@@ -2571,21 +2721,17 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
       const size_t T = (size_t)N * N;
       const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
       const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
-      if (!force_dense && g.Mp <= 8192) {
-        CCHK(hipMalloc(&h->rp, (size_t)L * (T + 1) * 4));
-        CCHK(hipMalloc(&h->tc, (size_t)L * T * 4));
+      const bool can_list = g.Mp <= 8192 && xm <= ENT_CMAX;   // 13-bit reporter field, 6-bit counts
+      if (!force_dense && can_list) {
+        unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
+        CCHK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
         unsigned long long* nnz_dev = nullptr;
         CCHK(hipMalloc(&nnz_dev, (size_t)L * 8));
         CCHK(hipMemsetAsync(nnz_dev, 0, (size_t)L * 8, h->stream));
         const unsigned cgrid = (unsigned)std::min<size_t>(8192, (T + 15) / 16);
-        for (int l = 0; l < L; ++l) {
-          if (g.mut)
-            hipLaunchKernelGGL(k_sp_count<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                               h->rp + (size_t)l * (T + 1), h->tc + (size_t)l * T, nnz_dev + l, g);
-          else
-            hipLaunchKernelGGL(k_sp_count<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                               h->rp + (size_t)l * (T + 1), h->tc + (size_t)l * T, nnz_dev + l, g);
-        }
+        for (int l = 0; l < L; ++l)
+          hipLaunchKernelGGL(k_sp_count, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                             rp + (size_t)l * (T + 1), nnz_dev + l, g);
         CCHK(hipGetLastError());
         CCHK(hipStreamSynchronize(h->stream));   // the stream is non-blocking: a plain hipMemcpy does not wait for it
         std::vector<unsigned long long> nl(L), eb(L);
@@ -2596,39 +2742,57 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
         for (int l = 0; l < L; ++l) { eb[l] = h->nnz; h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
         const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
         h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
-        {   // owner map of a wave: 1.5 x the average entries of a 64-tie step (denser steps are walked tie by tie)
-          const double per_step = 64.0 * (double)h->nnz / (double)rows;
-          long long ec = (long long)(1.5 * per_step / 256.0 + 1.0) * 256;
-          if (const char* fe = getenv("VMR_ECAP")) ec = atoll(fe);
-          g.ecap = (int)std::min<long long>(8192, std::max<long long>(1024, ec));
-        }
+        unsigned* bsum = nullptr;
         if (h->sparse) {
-          const size_t n = T + 1;
-          const unsigned nbs = (unsigned)((n + 2047) / 2048);
-          unsigned* bsum = nullptr;
-          CCHK(hipMalloc(&bsum, (size_t)nbs * 4));
+          const size_t n = T + 1, NS = (T + 63) / 64, n2 = 2 * NS + 1;
+          const unsigned nbs = (unsigned)((n + 2047) / 2048), nbs2 = (unsigned)((n2 + 2047) / 2048);
+          const unsigned sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
+          CCHK(hipMalloc(&bsum, (size_t)std::max(nbs, nbs2) * 4));
+          CCHK(hipMalloc(&h->rs, (size_t)L * n2 * 4));
+          // slot offsets of the steps (full rounds + rest, see k_sp_plan), then the per-tie offsets of the tie-major temp
           for (int l = 0; l < L; ++l) {
-            unsigned* rpl = h->rp + (size_t)l * n;
+            unsigned* rpl = rp + (size_t)l * n;
+            unsigned* rsl = h->rs + (size_t)l * n2;
+            hipLaunchKernelGGL(k_sp_plan, dim3(sgrid), dim3(256), 0, h->stream, rpl, rsl, g);
+            hipLaunchKernelGGL(k_scan_local, dim3(nbs2), dim3(256), 0, h->stream, rsl, bsum, n2);
+            hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs2);
+            hipLaunchKernelGGL(k_scan_add, dim3(nbs2), dim3(256), 0, h->stream, rsl, bsum, n2);
             hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
             hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs);
             hipLaunchKernelGGL(k_scan_add, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
           }
           CCHK(hipGetLastError());
+          CCHK(hipStreamSynchronize(h->stream));
+          std::vector<unsigned> slots(L);   // slots per layer (reports + padding)
+          for (int l = 0; l < L; ++l)
+            CCHK(hipMemcpy(&slots[l], h->rs + (size_t)l * n2 + 2 * NS, 4, hipMemcpyDeviceToHost));
+          // (a layer whose slots overflow 32 bits cannot happen below 2^32 reports with at most 2x padding ... but check)
+          h->n_slots = 0;
+          bool ok_slots = true;
+          for (int l = 0; l < L; ++l) { eb[l] = h->n_slots; h->n_slots += slots[l]; ok_slots = ok_slots && (double)slots[l] >= (double)nl[l]; }
+          if (!ok_slots) { CCHK(hipFree(bsum)); CCHK(hipFree(rp)); vmr_destroy(h); return fail(nullptr, VMR_EINVAL, "more than 2^32 report slots in one layer"); }
           CCHK(hipMalloc(&h->ebase, (size_t)L * 8));
           CCHK(hipMemcpyAsync(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
-          CCHK(hipMalloc(&h->E, ((size_t)h->nnz + 64) * 4));
+          CCHK(hipMalloc(&h->E, ((size_t)h->n_slots + 64) * 4));
           CCHK(hipMalloc(&h->Qt, rows * 4));
           CCHK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
+          unsigned* etmp = nullptr;   // one layer's entries in tie-major order
+          unsigned long long nlmax = 0;
+          for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
+          CCHK(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
           for (int l = 0; l < L; ++l) {
             if (g.mut)
               hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->tc + (size_t)l * T, h->E + eb[l], h->Qt + (size_t)l * T, g);
+                                 h->Rb + (size_t)l * T * g.W, rp + (size_t)l * n, etmp, h->Qt + (size_t)l * T, g);
             else
               hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, h->rp + (size_t)l * n, h->tc + (size_t)l * T, h->E + eb[l], h->Qt + (size_t)l * T, g);
+                                 h->Rb + (size_t)l * T * g.W, rp + (size_t)l * n, etmp, h->Qt + (size_t)l * T, g);
+            hipLaunchKernelGGL(k_sp_round, dim3(sgrid), dim3(256), 0, h->stream, rp + (size_t)l * n, h->rs + (size_t)l * n2,
+                               etmp, h->E + eb[l], g);
           }
           CCHK(hipGetLastError());
           CCHK(hipStreamSynchronize(h->stream));
+          CCHK(hipFree(etmp));
           // ---- mask lists for partial rows that hold few reporters (self-reporter masks: two per row) ----
           if (h->n_partial > 0 && !getenv("VMR_NO_RLISTS")) {
             unsigned long long* tot_dev = nullptr;
@@ -2679,39 +2843,54 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
           }
           CCHK(hipFree(bsum));
           if (!getenv("VMR_KEEP_X")) { CCHK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
-        } else {
-          CCHK(hipFree(h->rp));
-          CCHK(hipFree(h->tc));
-          h->rp = nullptr;
-          h->tc = nullptr;
         }
+        CCHK(hipFree(rp));
       } else if (force_sparse) {
         vmr_destroy(h);
-        return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192");
+        return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192 and counts <= 63");
       }
     }
-    // LDS levels of H (mirror counts 0..hc-1; higher counts are rare and go to global atomics, which are slow
-    // for scattered 8-byte adds): all of min(Y, HC_MAX) must fit.  Beside the rho pass' tables when that keeps
-    // >= 2 workgroups per CU resident (one pass per sweep); otherwise in the statistics pass alone (two passes).
+    // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
     g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
+    g.yt = 0;
     g.two_pass = 0;
     size_t need = 0;
     if (h->sparse) {
-      if (const char* fh = getenv("VMR_HC")) {   // experiment: force the number of LDS levels (one pass if it fits)
-        g.hc = std::max(0, std::min(atoi(fh), g.hc));
-        g.two_pass = shmem_sp(g, g.mut != 0, true, true) > 160000 ? 1 : 0;
-      } else if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
-        // wide reporter dimension.  Two levels beside the rho pass' tables (2 workgroups per CU) beat a second pass
-        // with three (M = 1000, K = 3, N = 3000: 3.0 vs 3.8 ms per sweep; ONE level: 14 ms, level 1 is populous)
-        const int hc3 = g.hc;
-        g.hc = std::min(g.hc, 2);
-        if (shmem_sp(g, g.mut != 0, false, true) > 80000) {
-          g.hc = hc3;
-          g.two_pass = 1;
-          while (g.hc > 0 && shmem_sp(g, false, false, true) > 160000) --g.hc;
+      // Report lists: both tables want the populous levels in LDS ([level][Mp][K] doubles each) beside 64 K doubles per
+      // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
+      // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
+      auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+      const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 8)));
+      auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {   // resident waves per CU: LDS and register limits
+        const size_t b = shmem_sp(g, tpb, yt, hc, upd, false, hist);
+        if (b > SP_LDS_MAX) return 0;
+        const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), (SP_WPE * 4) / nw);
+        return wgs * nw;
+      };
+      auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {   // most levels at >= min_waves per CU
+        for (int lv = want; lv >= 1; --lv) {
+          int bw = 0, bt = 256;
+          for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
+          if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
         }
+        return false;
+      };
+      int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
+      const bool one = best(true, true, 16, lv1, t1);
+      if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
+      else {
+        g.two_pass = 1;
+        if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
+        if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
+        g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
       }
-      need = std::max(shmem_sp(g, g.mut != 0, true, !g.two_pass), shmem_sp(g, false, false, true));
+      // experiments: force the shape
+      if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
+      g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
+      g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
+      { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
+      for (int v = 0; v < 4; ++v) need = std::max(need, sp_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
+      CCHK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
     } else {
       if (shmem_rho(g, true, false) > 80000) {
         g.two_pass = 1;
@@ -2719,8 +2898,8 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
       }
       need = std::max(shmem_rho(g, true, true), shmem_hist(g));
     }
-    // per-reporter tables live in LDS (E[log theta], the mutuality weights c[m,k], G_theta for the ELBO):
-    // (K + 2) * 8 bytes per reporter.  160 KB per workgroup on gfx950.
+    // per-reporter tables live in LDS (dense tiles: E[log theta], the mutuality weights c[m,k], G_theta for the ELBO:
+    // (K + 2) * 8 bytes per reporter).  160 KB per workgroup on gfx950.
     if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
       char msg[256];
       snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
@@ -2734,6 +2913,21 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
   CCHK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
   CCHK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
   CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
+  CCHK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
+  if (h->sparse) {
+    // the constants C[l][y][m] = sum of the counts per (mirror count, reporter): one statistics launch in count mode
+    CCHK(hipMalloc(&h->Cg, (size_t)L * g.Y * g.Mp * 8));
+    const SpShape sh = sp_shape(h, false, false, true);
+    SpArgs a = sp_args(h, sh, 2);
+    int rc = VMR_OK;
+    DISPATCH_K(g.K, rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb);
+               if (rc == VMR_OK) hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
+    if (rc != VMR_OK) { g_create_err = h->err; vmr_destroy(h); return rc; }
+    CCHK(hipGetLastError());
+    const size_t nit = (size_t)L * g.Y * g.Mp;
+    hipLaunchKernelGGL(k_take_counts, dim3((unsigned)std::min<size_t>(1024, (nit + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, h->Cg, g);
+    CCHK(hipGetLastError());
+  }
   CCHK(hipStreamSynchronize(h->stream));
 #undef CCHK
   *out = h;
@@ -2745,7 +2939,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rp, h->tc, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3027,7 +3221,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   const double SX = V, SR = V / 8.0, Srho = 8.0 * g.L * (double)g.N * g.N * g.K;
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
-    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties + g.L) + 4.0 * ties;   // entries; row pointers + class record
+    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (2.0 * ties / 64.0 + g.L);   // entries (without the rounds' padding); step pointers
     const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {
