@@ -230,20 +230,30 @@ def launch_ranks(n):
 
 
 def time_to_converge(cfg, net, eng, seed):
-    """BASELINE's second figure: one realisation of VimureModel.fit on the resident dataset until the reference's
-    stop rule fires (|dELBO| < 0.1 on two consecutive checks, checks at iteration 1 and every 10th; model.py:1036-1056).
+    """BASELINE's second figure: `VimureModel.fit` on the resident dataset until the reference's stop rule fires
+    (|dELBO| < 0.1 on two consecutive checks, checks at iteration 1 and every 10th; model.py:1036-1056), for one
+    realisation and for five (the next initial state is drawn on host threads while the GPU sweeps).
     Outside the timed region of `value`."""
     import warnings
     from vimure_amd import VimureModel
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        m = VimureModel(mutuality=cfg["mutuality"])
-        t0 = time.perf_counter()
-        m.fit(net.X, K=cfg["K"], seed=seed, engine=eng, num_realisations=1, max_iter=2000)
-        wall = time.perf_counter() - t0
-    return {"iterations": int(m.trace["iter"].max()), "converged": bool(m.trace["reached_convergence"].iloc[-1]),
-            "loop_seconds": m.loop_seconds, "fit_seconds": wall, "elbo": float(m.maxL),
-            "note": "fit_seconds adds the host-side RandomState draw of pr_rho, its upload and the read-back of rho"}
+    out = {}
+    for reals in (1, 5):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = VimureModel(mutuality=cfg["mutuality"])
+            t0 = time.perf_counter()
+            m.fit(net.X, K=cfg["K"], seed=seed, engine=eng, num_realisations=reals, max_iter=2000)
+            wall = time.perf_counter() - t0
+        d = {"iterations": m.trace.groupby("realisation")["iter"].max().tolist(),
+             "converged": bool(m.trace.groupby("realisation")["reached_convergence"].last().all()),
+             "loop_seconds": m.loop_seconds, "fit_seconds": wall, "waited_for_initial_states": m.draw_seconds, "elbo": float(m.maxL)}
+        if reals == 1:
+            out = dict(d, iterations=d["iterations"][0])
+        else:
+            out["five_realisations"] = d
+    out["note"] = ("fit_seconds = loop_seconds + the RandomState draw of pr_rho (bit-exact with the reference, parallel host "
+                   "threads), its upload and ONE read-back of rho at the end (the best realisation is kept on the device)")
+    return out
 
 
 def cpu_baseline(cfg, net, R, host, pr, budget_s, eng):

@@ -39,6 +39,9 @@ enum {
 /* sub-steps of one sweep, for vmr_sub_step (model.py:643-656) */
 enum { VMR_STEP_GAMMA = 0, VMR_STEP_PHI = 1, VMR_STEP_RHO = 2, VMR_STEP_NU = 3 };
 
+/* read-out methods for vmr_readout (model.py:1099-1188) */
+enum { VMR_READ_RHO_MAX = 0, VMR_READ_RHO_MEAN = 1, VMR_READ_THRESHOLD = 2 };
+
 /* kernel classes for vmr_profile_read */
 enum {
   VMR_KERNEL_GAMMA_MASK = 0,   /* masked reduction over R: A[l,m,k] = sum_ij R rho           */
@@ -123,6 +126,22 @@ int vmr_sub_step(vmr_handle h, int which);
  * (model.py:925-942).  Any pointer may be NULL.  Synchronises. */
 int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* phi_shp,
                   double* phi_rte, double* nu_shp, double* nu_rte, double* rho);
+
+/* Best-realisation bookkeeping on the device: vmr_snapshot keeps a copy of rho and of every parameter -- what
+ * `_update_optimal_parameters` copies into the `*_f` attributes (model.py:925-942), without moving rho (8 L N^2 K bytes)
+ * to the host after every realisation; vmr_restore makes the snapshot the current state again, so that
+ * vmr_get_state / vmr_get_geometric read the best realisation once, at the end of `fit`.  Asynchronous on the
+ * handle's stream. */
+int vmr_snapshot(vmr_handle h);
+int vmr_restore(vmr_handle h);
+
+/* Posterior read-out of the CURRENT rho on the device -- `get_inferred_model` (model.py:1099-1188) and
+ * `apply_rho_threshold` (utils.py:207-217) -- so that a 16 MB answer crosses PCIe instead of the 256 MB of rho:
+ *   VMR_READ_RHO_MAX    out uint8 [L,N,N]   argmax_k rho (first maximum, as np.argmax)
+ *   VMR_READ_RHO_MEAN   out double [L,N,N]  sum_k k rho_k
+ *   VMR_READ_THRESHOLD  out uint8 [L,N,N]   rho[...,1] >= threshold
+ * out_on_device != 0: `out` is a device pointer.  Synchronises. */
+int vmr_readout(vmr_handle h, int method, double threshold, void* out, int out_on_device);
 
 /* exp(E[log .]) of theta [L,M], lambda [L,K], nu from the current shape/rate parameters
  * (model.py:676-684), plus g_nu_cache = the G_exp_nu the last cache refresh held, i.e. the

@@ -84,3 +84,65 @@ def test_initial_draws_are_bit_exact(name):
     for n in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte"):
         assert np.array_equal(np.broadcast_to(getattr(m, n), d["init_" + n].shape), d["init_" + n]), n
     assert m.nu_shp == float(d["init_nu_shp"]) and m.nu_rte == float(d["init_nu_rte"])
+
+
+@pytest.mark.parametrize("L,N,K,bias,seed", [(1, 9, 2, 0.0, 1), (2, 21, 3, 0.2, 7), (1, 30, 5, 0.0, 12345), (2, 600, 2, 0.0, 4)])
+def test_one_pass_draw_is_bit_identical_to_the_numpy_statements(L, N, K, bias, seed):
+    """vimure_amd/csrc/host_init.c against the reference's statements (model.py:470-482, 536-556): same doubles,
+    same RandomState stream afterwards (the gamma draws and the next seed follow it)."""
+    from vimure_amd import _hostlib
+    if _hostlib.load() is None:
+        pytest.skip("no C compiler for the host helper")
+    a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+    a.random_sample(5), b.random_sample(5)   # a generator state in the middle of a block
+    cov = (np.random.RandomState(3).rand(L, N, N) < 0.6).astype(np.uint8)
+    pr = 1.0 + 0.01 * a.rand(L, N, N, K)
+    pr[..., 0] += bias
+    pr /= pr.sum(axis=-1)[..., None]
+    onehot = np.zeros(K)
+    onehot[0] = 1.0
+    pr[cov == 0] = onehot
+    out = np.empty((L, N, N, K))
+    got = _hostlib.draw_pr_rho(b, (L, N, N, K), bias, cov, out=out)
+    assert got is not None and np.array_equal(got, pr) and np.shares_memory(got, out)
+    assert np.array_equal(a.random_sample((L, 7)), b.random_sample((L, 7)))
+    assert a.randint(1, 500) == b.randint(1, 500)
+
+
+def test_initial_states_follow_the_reference_seed_chain():
+    """`_initial_states` (drawn ahead of the GPU loop) yields what realisation-by-realisation draws yield."""
+    from vimure_amd.model import VimureModel
+
+    class FakeEngine:
+        def __init__(self, shape):
+            self.bufs = {}
+            self.shape = shape
+
+        def staging(self, i):
+            return self.bufs.setdefault(i, np.empty(self.shape))
+
+    L, N, M, K = 2, 11, 6, 3
+    cov = (np.random.RandomState(5).rand(L, N, N) < 0.8).astype(np.uint8)
+
+    def mk():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = VimureModel()
+        m.L, m.N, m.M, m.K = L, N, M, K
+        m.alpha_theta, m.beta_theta, m.alpha_lambda, m.beta_lambda = 0.1, 0.1, 10.0, 10.0
+        m.alpha_mutuality, m.beta_mutuality, m.rho_prior = 0.5, 1.0, None
+        m.num_realisations, m.bias0, m.sumX = 7, 0.3, 123.0
+        m._change_seed(11)
+        return m
+    a, b = mk(), mk()
+    got = [(r, s, {k: np.copy(v) for k, v in st.items()}, nxt) for r, s, st, nxt in a._initial_states(FakeEngine((L, N, N, K)), cov)]
+    for r in range(7):   # the reference's order: prior, gammas, randint, reseed (model.py:386-437)
+        bias = 0.0 if r < 5 else (r - 4) * 0.3
+        pr = b._draw_pr_rho(cov, bias)
+        st = b._draw_gammas(123.0)
+        assert got[r][0] == r and got[r][1] == b.seed
+        assert np.array_equal(got[r][2]["pr_rho"], pr)
+        for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):
+            assert np.array_equal(got[r][2][k], st[k])
+        b._change_seed(b.seed + b.prng.randint(1, 500))
+        assert got[r][3] == b.seed

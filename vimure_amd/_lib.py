@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("VMR_LIB", os.path.join(HERE, "libvimure_hip.so"))  # 
 VMR_OK, VMR_EINVAL, VMR_EHIP, VMR_ENAN, VMR_ESTATE = 0, -1, -2, -3, -4
 STEP_GAMMA, STEP_PHI, STEP_RHO, STEP_NU = 0, 1, 2, 3
 KERNEL_GAMMA_MASK, KERNEL_GAMMA_COUNTS, KERNEL_PHI, KERNEL_RHO, KERNEL_ELBO, KERNEL_FINALIZE, KERNEL_RHO_ELBO = range(7)
+READ_RHO_MAX, READ_RHO_MEAN, READ_THRESHOLD = 0, 1, 2
 KERNEL_NAMES = ["gamma_mask", "gamma_counts", "phi", "rho", "elbo", "finalize", "rho_elbo"]
 
 _dp = C.POINTER(C.c_double)
@@ -34,6 +35,9 @@ SIGNATURES = {
     "vmr_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "vmr_get_geometric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vmr_sync": (C.c_int, [C.c_void_p]),
+    "vmr_readout": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]),
+    "vmr_snapshot": (C.c_int, [C.c_void_p]),
+    "vmr_restore": (C.c_int, [C.c_void_p]),
     "vmr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_profile_read": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "vmr_kernel_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),

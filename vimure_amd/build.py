@@ -7,6 +7,8 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "vimure_hip.hip")
 LIB = os.path.join(HERE, "libvimure_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOST_SRC = os.path.join(HERE, "csrc", "host_init.c")
+HOST_LIB = os.path.join(HERE, "libvimure_host.so")
 
 
 def needs_build() -> bool:
@@ -27,5 +29,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The host-side helper (initial-state draw, plain C): gcc, no FMA contraction (NumPy rounds twice)."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    cmd = [os.environ.get("CC", "gcc"), "-O3", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-o", HOST_LIB, HOST_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
+    print(build_host(force=True, verbose=True))
     print(build(force=True, verbose=True))

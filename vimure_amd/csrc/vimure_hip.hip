@@ -107,6 +107,8 @@ struct vmr_ctx {
   // state
   double *rho = nullptr, *logpr = nullptr;
   double* par = nullptr;       // parameter block, see P_* offsets
+  double *rho_snap = nullptr, *par_snap = nullptr;   // vmr_snapshot: the best realisation so far (model.py:925-942)
+  bool have_snap = false;
   size_t par_doubles = 0;
   // partials
   double *slotA = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
@@ -2294,6 +2296,26 @@ __global__ void k_commit_nu(double* par, double nu_partial_total, Geo g) {
   }
 }
 
+// posterior read-out per tie (model.py:1099-1188, utils.py:200-217): argmax_k rho, sum_k k rho_k, rho_1 >= threshold
+__global__ __launch_bounds__(256) void k_readout(const double* __restrict__ rho, void* __restrict__ out, size_t ties, int K,
+                                                 int method, double threshold) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ties; t += (size_t)gridDim.x * blockDim.x) {
+    const double* r = rho + t * K;
+    if (method == VMR_READ_RHO_MAX) {
+      int best = 0;
+      double bv = r[0];
+      for (int k = 1; k < K; ++k) if (r[k] > bv) { bv = r[k]; best = k; }   // first maximum, as np.argmax
+      reinterpret_cast<uint8_t*>(out)[t] = (uint8_t)best;
+    } else if (method == VMR_READ_RHO_MEAN) {
+      double m = 0.0;
+      for (int k = 1; k < K; ++k) m += (double)k * r[k];
+      reinterpret_cast<double*>(out)[t] = m;
+    } else {
+      reinterpret_cast<uint8_t*>(out)[t] = r[1] >= threshold ? 1 : 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -2939,7 +2961,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* ptrs[] = {h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3159,6 +3181,54 @@ int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g
   if (g_nu && (rc = d2h(h, g_nu, h->par + o.sc + SC_G_NU, 8))) return rc;
   if (g_nu_cache && (rc = d2h(h, g_nu_cache, h->par + o.sc + SC_G_NU_STALE, 8))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return VMR_OK;
+}
+
+// `_update_optimal_parameters` (model.py:925-942) without a host round trip: keep a device copy of the posteriors
+int vmr_snapshot(vmr_handle h) {
+  if (!h) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_snapshot");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Geo& g = h->g;
+  const size_t nr = (size_t)g.L * g.N * g.N * g.K * 8, np_ = h->par_doubles * 8;
+  if (!h->rho_snap) { HIPCHK(h, hipMalloc(&h->rho_snap, nr)); HIPCHK(h, hipMalloc(&h->par_snap, np_)); }
+  HIPCHK(h, hipMemcpyAsync(h->rho_snap, h->rho, nr, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->par_snap, h->par, np_, hipMemcpyDeviceToDevice, h->stream));
+  h->have_snap = true;
+  return VMR_OK;
+}
+
+// make the snapshot the current state again (rho and every parameter; the statistics are rebuilt on the next sweep)
+int vmr_restore(vmr_handle h) {
+  if (!h) return VMR_EINVAL;
+  if (!h->have_snap) return fail(h, VMR_ESTATE, "vmr_snapshot must be called before vmr_restore");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Geo& g = h->g;
+  HIPCHK(h, hipMemcpyAsync(h->rho, h->rho_snap, (size_t)g.L * g.N * g.N * g.K * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->par, h->par_snap, h->par_doubles * 8, hipMemcpyDeviceToDevice, h->stream));
+  h->h_valid = false; h->f_valid = false; h->ftab_valid = false; h->h_zero = false;
+  HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
+  hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+
+int vmr_readout(vmr_handle h, int method, double threshold, void* out, int out_on_device) {
+  if (!h || !out) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_readout");
+  if (method < VMR_READ_RHO_MAX || method > VMR_READ_THRESHOLD) return fail(h, VMR_EINVAL, "unknown read-out method");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Geo& g = h->g;
+  const size_t ties = (size_t)g.L * g.N * g.N, bytes = ties * (method == VMR_READ_RHO_MEAN ? 8 : 1);
+  void* dst = out;
+  if (!out_on_device) HIPCHK(h, hipMalloc(&dst, bytes));
+  hipLaunchKernelGGL(k_readout, dim3((unsigned)std::min<size_t>(4096, (ties + 255) / 256)), dim3(256), 0, h->stream, h->rho, dst, ties,
+                     g.K, method, threshold);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (!out_on_device) (void)hipFree(dst);
+  if (e != hipSuccess) { h->err = std::string("vmr_readout: ") + hipGetErrorString(e); (void)hipGetLastError(); return VMR_EHIP; }
   return VMR_OK;
 }
 

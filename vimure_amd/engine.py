@@ -23,9 +23,24 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def host_buffer(n_doubles, pinned=True):
+    """float64 staging buffer for rho-sized transfers: page-locked (through torch) when that is available and worth it."""
+    if pinned and n_doubles * 8 >= (8 << 20):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                t = torch.empty(int(n_doubles), dtype=torch.float64, pin_memory=True)
+                a = t.numpy()
+                return a, t   # (the tensor owns the memory: keep it alive with the array)
+        except Exception:
+            pass
+    return np.empty(int(n_doubles), np.float64), None
+
+
 class CaviEngine:
     def __init__(self, X, R=None, K=2, mutuality=True, eps=1e-12, device=None):
         self._h = C.c_void_p()
+        self._staging = []   # pinned float64 buffers reused across realisations / fits on this engine
         self.lib = _lib.load()
         on_dev = _is_torch(X)
         if on_dev:
@@ -70,6 +85,12 @@ class CaviEngine:
         if rc in (_lib.VMR_EINVAL, _lib.VMR_ENAN):
             raise ValueError(msg)
         raise EngineError(msg)
+
+    def staging(self, i):
+        """The i-th rho-sized host staging buffer of this engine (allocated on first use, pinned when possible)."""
+        while len(self._staging) <= i:
+            self._staging.append(host_buffer(self.L * self.N * self.N * self.K))
+        return self._staging[i][0].reshape(self.L, self.N, self.N, self.K)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -144,13 +165,33 @@ class CaviEngine:
     def sync(self):
         self._check(self.lib.vmr_sync(self._h))
 
-    def get_state(self, rho=True):
+    def readout(self, method, threshold=0.0):
+        """Read-out of the current rho on the device: "rho_max" / "threshold" -> uint8 [L,N,N], "rho_mean" -> float64."""
+        code = {"rho_max": _lib.READ_RHO_MAX, "rho_mean": _lib.READ_RHO_MEAN, "threshold": _lib.READ_THRESHOLD}[method]
+        out = np.empty((self.L, self.N, self.N), np.float64 if method == "rho_mean" else np.uint8)
+        self._check(self.lib.vmr_readout(self._h, code, float(threshold), out.ctypes.data, 0))
+        return out
+
+    def snapshot(self):
+        """Keep the current posteriors on the device (`_update_optimal_parameters`, reference model.py:925-942)."""
+        self._check(self.lib.vmr_snapshot(self._h))
+
+    def restore(self):
+        """Make the snapshot the current state again."""
+        self._check(self.lib.vmr_restore(self._h))
+
+    def get_state(self, rho=True, rho_out=None):
+        """Posteriors as NumPy arrays; rho_out: a C-contiguous float64 buffer to receive rho (e.g. pinned memory)."""
         out = {
             "gamma_shp": np.empty((self.L, self.M)), "gamma_rte": np.empty((self.L, self.M)),
             "phi_shp": np.empty((self.L, self.K)), "phi_rte": np.empty((self.L, self.K)),
         }
         ns, nr = C.c_double(), C.c_double()
-        r = np.empty((self.L, self.N, self.N, self.K)) if rho else None
+        r = None
+        if rho:
+            r = rho_out if rho_out is not None else np.empty((self.L, self.N, self.N, self.K))
+            assert r.dtype == np.float64 and r.flags.c_contiguous and r.size == self.L * self.N * self.N * self.K
+            r = r.reshape(self.L, self.N, self.N, self.K)
         self._check(self.lib.vmr_get_state(
             self._h, out["gamma_shp"].ctypes.data, out["gamma_rte"].ctypes.data, out["phi_shp"].ctypes.data,
             out["phi_rte"].ctypes.data, C.addressof(ns), C.addressof(nr), r.ctypes.data if rho else None))

@@ -18,7 +18,7 @@ import scipy.special as sp
 from scipy.stats import poisson
 
 from ._log import setup_logging
-from .engine import CaviEngine
+from .engine import CaviEngine, host_buffer
 from .tensor import is_sparse_like, to_dense_u8
 
 try:  # the reference is an sklearn estimator (model.py:28); keep that surface when sklearn is there
@@ -38,7 +38,7 @@ DEFAULT_NUM_REALISATIONS = 1
 
 _EXTRA = ["R", "EPS", "K", "bias0", "max_iter", "alpha_lambda", "beta_lambda", "alpha_teta", "beta_teta",
           "num_realisations"]  # the reference's whitelist, typos included (model.py:90-101)
-_OURS = ["device", "alpha_theta", "beta_theta", "engine"]
+_OURS = ["device", "alpha_theta", "beta_theta", "engine", "keep_engine"]
 
 
 def _is_torch(x):
@@ -178,10 +178,18 @@ class VimureModel(TransformerMixin, BaseEstimator):
         self.prng = np.random.RandomState(seed)
 
     # ------------------------------------------------------------------ initial state (model.py:458-605)
-    def _draw_pr_rho(self, coverage, bias0):
+    def _draw_pr_rho(self, coverage, bias0, prng=None, out=None):
+        """`_set_rho_prior` (model.py:458-559).  The common case (no informative prior, directed network) runs as one C
+        pass that is bit-identical to the NumPy statements below (vimure_amd/csrc/host_init.c), into `out` if given."""
+        prng = self.prng if prng is None else prng
         L, N, K = self.L, self.N, self.K
+        if self.rho_prior is None and not self.undirected:
+            from . import _hostlib
+            pr = _hostlib.draw_pr_rho(prng, (L, N, N, K), bias0, coverage, out=out)
+            if pr is not None:
+                return pr
         if self.rho_prior is None:
-            pr = 1.0 + 0.01 * self.prng.rand(L, N, N, K)
+            pr = 1.0 + 0.01 * prng.rand(L, N, N, K)
             pr[..., 0] += bias0
             if self.undirected:
                 pr = (pr + pr.transpose(0, 2, 1, 3)) / 2.0
@@ -191,53 +199,118 @@ class VimureModel(TransformerMixin, BaseEstimator):
             sub = np.nonzero(self.rho_prior)
             n = sub[0].shape[0]
             for k in range(K):
-                pr[sub + (np.full(n, k),)] = poisson.pmf(k, self.rho_prior[sub]) + 1.0 * self.prng.rand(n)
+                pr[sub + (np.full(n, k),)] = poisson.pmf(k, self.rho_prior[sub]) + 1.0 * prng.rand(n)
             if self.undirected:
                 pr = (pr + pr.transpose(0, 2, 1, 3)) / 2.0
             pr[sub] /= pr[sub].sum(axis=-1)[:, None]
         onehot = np.zeros(K)
         onehot[0] = 1.0
         pr[coverage == 0] = onehot  # ties no reporter covers / nobody reported (model.py:508-556)
+        if out is not None:
+            out[...] = pr
+            return out
         return pr
 
-    def _draw_gammas(self, sumX):
+    def _draw_gammas(self, sumX, prng=None):
+        """`_initialize_priors` (model.py:561-605): the draws that follow the rho prior, in the reference's order."""
+        prng = self.prng if prng is None else prng
         L, M, K = self.L, self.M, self.K
-        self.gamma_shp = self.alpha_theta * self.prng.random_sample(size=(L, M)) + self.alpha_theta
-        self.phi_shp = self.alpha_lambda * self.prng.random_sample(size=(L, K)) + self.alpha_lambda
-        self.gamma_rte = self.beta_theta * self.prng.random_sample(size=(L, M)) + self.beta_theta
-        self.phi_rte = self.beta_lambda * self.prng.random_sample(size=(L, K)) + self.beta_lambda
+        st = {}
+        st["gamma_shp"] = self.alpha_theta * prng.random_sample(size=(L, M)) + self.alpha_theta
+        st["phi_shp"] = self.alpha_lambda * prng.random_sample(size=(L, K)) + self.alpha_lambda
+        st["gamma_rte"] = self.beta_theta * prng.random_sample(size=(L, M)) + self.beta_theta
+        st["phi_rte"] = self.beta_lambda * prng.random_sample(size=(L, K)) + self.beta_lambda
         if self.mutuality:
-            self.nu_shp = self.alpha_mutuality * self.prng.random_sample(1)[0] + self.alpha_mutuality
-            self.nu_rte = self.beta_mutuality + sumX  # fixed once and for all (model.py:593-595)
+            st["nu_shp"] = self.alpha_mutuality * prng.random_sample(1)[0] + self.alpha_mutuality
+            st["nu_rte"] = self.beta_mutuality + sumX  # fixed once and for all (model.py:593-595)
         else:
-            self.nu_shp, self.nu_rte = 0.000001, 1.0
+            st["nu_shp"], st["nu_rte"] = 0.000001, 1.0
+        if prng is self.prng:
+            for k, v in st.items():
+                setattr(self, k, v)
+        return st
+
+    def _initial_states(self, eng, coverage):
+        """Initial state of every realisation, in order: (r, seed of r, state dict incl. pr_rho, seed after r).  CAVI
+        consumes no randomness (reference model.py:386-437), so the whole seed chain is a function of the first seed
+        and realisation r + 1 can be drawn while r runs on the GPU.  pr_rho lands in the engine's staging buffers
+        (three in rotation: one being uploaded, one queued, one being drawn)."""
+        seed, prng = self.seed, self.prng
+        for r in range(self.num_realisations):
+            bias = DEFAULT_BIAS0 if r < 5 else (r - 4) * self.bias0
+            pr = self._draw_pr_rho(coverage, bias, prng=prng, out=eng.staging(r % 3))
+            st = self._draw_gammas(self.sumX, prng=prng)
+            st["pr_rho"] = pr
+            step = prng.randint(1, 500)
+            nxt = step if seed is None else seed + step
+            yield r, seed, st, nxt
+            seed, prng = nxt, np.random.RandomState(nxt)
 
     # ------------------------------------------------------------------ fit (model.py:327-448)
     def fit(self, X, theta_prior=(0.1, 0.1), lambda_prior=(10.0, 10.0), eta_prior=(0.5, 1.0), rho_prior=None,
             seed: int = None, **extra_params):
         """Same contract as the reference's `fit`; extra keywords: `device` picks the GPU (default 0, or the
         device of a torch tensor X); `engine` reuses a `CaviEngine` already holding this X, R, K (many seeds
-        of one dataset: the data is uploaded once, see vimure_amd/batch.py)."""
+        of one dataset: the data is uploaded once, see vimure_amd/batch.py); `keep_engine=True` leaves the posteriors on
+        the GPU after the fit: `get_inferred_model` / `predict` then run there (vmr_readout) and `rho_f` is only copied
+        to the host if something asks for it (`close()` frees the device memory).
+
+        Host work per realisation is the RandomState draw of the initial state (bit-exact with the reference); with
+        several realisations the next draw runs on a host thread while the GPU sweeps, the best realisation is kept on
+        the device (vmr_snapshot) and rho crosses PCIe once, at the end.  `rho` (without `_f`) holds the best
+        realisation too (the reference leaves the last one there; nothing reads it after `fit`)."""
         Xd, Rd = self._check_fit_params(X, lambda_prior, theta_prior, eta_prior, rho_prior, seed, **extra_params)
+        self.close()   # a device state kept by an earlier fit(keep_engine=True)
+        self._engine, self._rho_f = None, None
         eng = extra_params.get("engine")
         own_engine = eng is None
+        keep = bool(extra_params.get("keep_engine", False)) and own_engine
         if own_engine:
             eng = CaviEngine(Xd, Rd, K=self.K, mutuality=self.mutuality, eps=self.EPS, device=extra_params.get("device"))
         elif (eng.L, eng.N, eng.M, eng.K, eng.mutuality) != (self.L, self.N, self.M, self.K, bool(self.mutuality)):
             raise ValueError("engine does not match the shape / K / mutuality of this fit")
+        producer = None
         try:
             self.sumX, coverage = eng.data_stats()
             eng.set_priors(self.alpha_theta, self.beta_theta, self.alpha_lambda, self.beta_lambda,
                            self.alpha_mutuality, self.beta_mutuality)
-            maxL, trace = -INF, []
+            maxL, trace, best = -INF, [], None
             self.loop_seconds = 0.0   # wall time inside the CAVI loops of all realisations (device work included)
-            for r in range(self.num_realisations):
-                bias = DEFAULT_BIAS0 if r < 5 else (r - 4) * self.bias0
-                pr_rho = self._draw_pr_rho(coverage, bias)
-                self._draw_gammas(self.sumX)
-                eng.set_state(self.gamma_shp, self.gamma_rte, self.phi_shp, self.phi_rte, self.nu_shp, self.nu_rte,
-                              pr_rho)
-                del pr_rho
+            self.draw_seconds = 0.0   # host time the loops waited for an initial state
+            states = self._initial_states(eng, coverage)
+            if self.num_realisations > 1:   # draw realisation r + 1 while r runs
+                import queue
+                import threading
+                q = queue.Queue(maxsize=1)   # one finished state waits while the next is drawn (three staging buffers)
+
+                def work():
+                    try:
+                        for item in states:
+                            q.put(item)
+                        q.put(None)
+                    except BaseException as e:   # surfaces in the consumer
+                        q.put(e)
+                producer = threading.Thread(target=work, daemon=True)
+                producer.start()
+
+                def next_state():
+                    item = q.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    return item
+            else:
+                def next_state():
+                    return next(states, None)
+            final_seed = self.seed
+            while True:
+                t_draw = time.perf_counter()
+                item = next_state()
+                self.draw_seconds += time.perf_counter() - t_draw
+                if item is None:
+                    break
+                r, seed_r, st, final_seed = item
+                eng.set_state(st["gamma_shp"], st["gamma_rte"], st["phi_shp"], st["phi_rte"], st["nu_shp"], st["nu_rte"],
+                              st["pr_rho"])   # (synchronises: the staging buffer is free again)
                 coincide, it, reached, elbo = 0, 1, False, -INF
                 t_loop = time.perf_counter()
                 while not reached and it <= self.max_iter:
@@ -256,16 +329,28 @@ class VimureModel(TransformerMixin, BaseEstimator):
                                           f"Reached convergence: {reached}")
                     it += 1
                     if (it - 1) % 10 == 0:
-                        trace.append((r, self.seed, it - 1, elbo, runtime, reached))
+                        trace.append((r, seed_r, it - 1, elbo, runtime, reached))
                 eng.sync()
                 self.loop_seconds += time.perf_counter() - t_loop
-                self._pull_state(eng)
+                self._pull_params(eng)   # the small arrays of this realisation (rho stays on the device)
                 if maxL < elbo:
-                    self._update_optimal_parameters()
-                    maxL = elbo
-                step = self.prng.randint(1, 500)
-                self._change_seed(step if self.seed is None else self.seed + step)
+                    maxL, best = elbo, self._params_copy()
+                    if self.num_realisations > 1:
+                        eng.snapshot()
+            if best is not None:
+                if self.num_realisations > 1:
+                    eng.restore()
+                self._update_optimal_parameters(best, eng, lazy_rho=keep)
+            self._change_seed(final_seed)
+            if keep:
+                self._engine, own_engine = eng, False
         finally:
+            if producer is not None and producer.is_alive():   # an exception left the producer blocked on its queue
+                try:
+                    while producer.is_alive():
+                        q.get(timeout=0.1)
+                except Exception:
+                    pass
             if own_engine:
                 eng.close()
         cols = ["realisation", "seed", "iter", "elbo", "runtime", "reached_convergence"]
@@ -273,26 +358,73 @@ class VimureModel(TransformerMixin, BaseEstimator):
         self.maxL = maxL
         return self
 
-    def _pull_state(self, eng):
-        st = eng.get_state(rho=True)
+    _SMALL = ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "nu_rte")
+
+    def _pull_params(self, eng):
+        st = eng.get_state(rho=False)
         self.gamma_shp, self.gamma_rte = st["gamma_shp"], st["gamma_rte"]
         self.phi_shp, self.phi_rte = st["phi_shp"], st["phi_rte"]
         self.nu_shp, self.nu_rte = np.float64(st["nu_shp"]), np.float64(st["nu_rte"])
-        self.rho = st["rho"]
         self.G_exp_theta = np.exp(sp.psi(self.gamma_shp) - np.log(self.gamma_rte))
         self.G_exp_lambda = np.exp(sp.psi(self.phi_shp) - np.log(self.phi_rte))
         # what the last cache refresh held, i.e. computed before the last nu update (model.py:684 vs :822)
         self.G_exp_nu = np.float64(eng.get_geometric()[3]) if self.mutuality else 0.0
 
-    def _update_optimal_parameters(self):
-        """model.py:925-942"""
-        self.gamma_shp_f, self.gamma_rte_f = np.copy(self.gamma_shp), np.copy(self.gamma_rte)
-        self.phi_shp_f, self.phi_rte_f = np.copy(self.phi_shp), np.copy(self.phi_rte)
-        self.nu_shp_f, self.nu_rte_f = np.copy(self.nu_shp), np.copy(self.nu_rte)
-        self.rho_f = np.copy(self.rho)
+    def _params_copy(self):
+        return {k: np.copy(getattr(self, k)) for k in self._SMALL}
+
+    def _update_optimal_parameters(self, best, eng, lazy_rho=False):
+        """model.py:925-942; rho of the best realisation is the engine's current state here (vmr_restore)."""
+        self.gamma_shp_f, self.gamma_rte_f = best["gamma_shp"], best["gamma_rte"]
+        self.phi_shp_f, self.phi_rte_f = best["phi_shp"], best["phi_rte"]
+        self.nu_shp_f, self.nu_rte_f = best["nu_shp"], best["nu_rte"]
+        self._rho_f = None
+        if not lazy_rho:
+            self._fetch_rho(eng)
         self.G_exp_theta_f = np.exp(sp.psi(self.gamma_shp_f) - np.log(self.gamma_rte_f))
         self.G_exp_lambda_f = np.exp(sp.psi(self.phi_shp_f) - np.log(self.phi_rte_f))
         self.G_exp_nu_f = np.exp(sp.psi(self.nu_shp_f) - np.log(self.nu_rte_f))
+
+    # rho_f / rho: on the host once fetched; with fit(keep_engine=True) still on the GPU until something reads them
+    def _fetch_rho(self, eng):
+        buf, keepalive = host_buffer(self.L * self.N * self.N * self.K)
+        self._rho_f = eng.get_state(rho=True, rho_out=buf)["rho"]
+        self._rho_keepalive = keepalive   # page-locked memory behind rho_f, when it is
+        return self._rho_f
+
+    @property
+    def rho_f(self):
+        if getattr(self, "_rho_f", None) is None:
+            eng = getattr(self, "_engine", None)
+            if eng is None:
+                raise AttributeError("rho_f: the model has not been fitted")
+            self._fetch_rho(eng)
+        return self._rho_f
+
+    @rho_f.setter
+    def rho_f(self, value):
+        self._rho_f = value
+
+    @property
+    def rho(self):
+        return self.rho_f
+
+    def close(self):
+        """Free the device state kept by fit(keep_engine=True); rho_f is fetched first if nothing has read it yet."""
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            if getattr(self, "_rho_f", None) is None:
+                self._fetch_rho(eng)
+            eng.close()
+            self._engine = None
+
+    def __del__(self):
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            try:
+                eng.close()
+            except Exception:
+                pass
 
     # ------------------------------------------------------------------ read-out (model.py:1062-1214)
     def sample_inferred_model(self, N=1, seed=None):
@@ -309,20 +441,29 @@ class VimureModel(TransformerMixin, BaseEstimator):
         options = ["rho_max", "rho_mean", "fixed_threshold", "heuristic_threshold"]
         if method not in options:
             raise ValueError("'method' should be one of {}.".format(", ".join(['"' + x + '"' for x in options])))
-        if (not self.mutuality and method != "rho_max") or (self.rho_f.shape[-1] > 2 and "threshold" in method):
+        if (not self.mutuality and method != "rho_max") or (self.K > 2 and "threshold" in method):
             msg = ('threshold methods is incompatible with VIMuRe\'s mutuality=False '
                    'or for data with more than 2 categories. Using "rho_max" method.')
             warnings.warn(msg, UserWarning)
             method = "rho_max"
+        # rho still on the GPU (fit(keep_engine=True), nothing has read rho_f): the read-out runs there (vmr_readout)
+        dev = getattr(self, "_engine", None) if getattr(self, "_rho_f", None) is None else None
         if method == "rho_max":
+            if dev is not None:
+                return dev.readout("rho_max").astype("int")
             return np.argmax(self.rho_f, axis=-1).astype("int")
         if method == "rho_mean":
+            if dev is not None:
+                return dev.readout("rho_mean")
             return np.dot(self.rho_f, range(0, self.rho_f.shape[-1]))
         if method == "fixed_threshold":
             if threshold is None or threshold > 1 or threshold < 0:
                 raise ValueError('For method="fixed_threshold", you must set the threshold to a value in [0,1].')
         else:  # heuristic threshold, reference utils.py:200-217
             threshold = 0.54 * self.G_exp_nu - 0.01
+        if dev is not None:
+            Y = dev.readout("threshold", threshold)
+            return Y.astype(np.float64) if method == "fixed_threshold" else Y.astype("int")
         Y = np.copy(self.rho_f[:, :, :, 1])
         Y[Y < threshold] = 0
         Y[Y >= threshold] = 1
