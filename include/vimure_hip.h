@@ -56,9 +56,10 @@ enum {
 
 /*
  * Dataset handle.  Replaces the data set-up half of `__check_fit_params`
- * (model.py:134-213): X is kept as dense uint8 counts (rows padded to 16 B), R is packed to
- * one bit per (l,i,j,m); X^T (model.py:141-161 `data_T`, `data_T_vals`) is never
- * materialised -- kernels read the mirrored tile instead.
+ * (model.py:134-213).  The dense count tensor is turned into REPORT LISTS on the device -- one 4-byte entry per non-zero
+ * count carrying the mirrored count X[l,j,i,m], so X^T (model.py:141-161 `data_T`, `data_T_vals`) is never
+ * materialised -- and then freed; tensors that are not sparse enough (or hold counts above 63, or M > 8192) stay as
+ * dense uint8 tiles with R packed to one bit per (l,i,j,m).  vmr_data_format tells which.
  *   X  [L,N,N,M] uint8 counts (values <= 255).
  *   R  [L,N,N,M] uint8 0/1, or NULL = every reporter may report on every tie
  *      (model.py:206-211 default).
@@ -69,6 +70,22 @@ enum {
  */
 int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality,
                const uint8_t* X, const uint8_t* R, int data_on_device, double eps);
+
+/*
+ * The same dataset handle from COORDINATE LISTS -- what the reference actually holds: `X.subs` / `X.vals` of the
+ * sptensor built by `read_from_edgelist` (_io.py:132-295) or `preprocess` (utils.py:220-248), and `R.subs` of a sparse
+ * reporter mask; `__check_fit_params` derives `data_T_vals` from them with an O(nnz^2) lookup (model.py:148-161).  No dense
+ * [L,N,N,M] tensor is built anywhere: the lists are sorted on the device and become the report lists directly.
+ *   nx reports: xl, xi, xj, xm (int32 subscripts) and xv (counts, 1..63); no duplicates.
+ *   nr mask entries rl, ri, rj, rm (R = 1 there, 0 elsewhere); nr < 0: every reporter may report on every tie
+ *   (model.py:206-211).
+ *   data_on_device != 0: all index arrays are device pointers on `device`.
+ * Needs M <= 8192; counts above 63 or wider tensors go through vmr_create.
+ */
+int vmr_create_coo(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality,
+                   int64_t nx, const int32_t* xl, const int32_t* xi, const int32_t* xj, const int32_t* xm, const int32_t* xv,
+                   int64_t nr, const int32_t* rl, const int32_t* ri, const int32_t* rj, const int32_t* rm,
+                   int data_on_device, double eps);
 
 void vmr_destroy(vmr_handle h);
 
@@ -101,6 +118,16 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
  * unless elbo_out != NULL, in which case the ELBO (`__ELBO`, model.py:948-1019) is reduced
  * inside the last sweep's rho pass and returned (this synchronises). */
 int vmr_step(vmr_handle h, int n_iters, double* elbo_out);
+
+/* The convergence loop of `fit` for the realisation set up by vmr_set_state (model.py:405-426 with the stop rule of
+ * `_check_for_convergence`, model.py:1021-1056): sweeps until the ELBO -- evaluated at iteration 1, every 10th and
+ * max_iter -- has changed by less than `tol` on more than `decision` consecutive evaluations, or max_iter is reached.
+ * Trace rows as the reference appends them (iterations that are multiples of 10, model.py:423-426): iteration, ELBO,
+ * wall time of that iteration's sweep in seconds, reached flag; at most `cap` rows.  *elbo = last ELBO, *iters =
+ * iterations run, *converged = the stop rule fired.  One call per realisation instead of one per iteration: host
+ * threads that drive several small fits at once then meet in the GPU, not in the caller's interpreter. */
+int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter, double* row_elbo,
+                 double* row_runtime, int* row_reached, double* elbo, int* iters, int* converged);
 
 /* Stand-alone ELBO of the current state (model.py:948-1019 incl. the stale G_exp_nu of
  * model.py:970).  Synchronises.  Returns VMR_ENAN when the value is NaN. */

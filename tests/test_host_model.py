@@ -146,3 +146,56 @@ def test_initial_states_follow_the_reference_seed_chain():
             assert np.array_equal(got[r][2][k], st[k])
         b._change_seed(b.seed + b.prng.randint(1, 500))
         assert got[r][3] == b.seed
+
+
+def test_karnataka_tables_match_the_reference_loops():
+    """`karnataka_tables` (vectorised) against a literal restatement of the reference driver's per-dyad / per-node loops
+    (notebooks/python/experiments/karnataka.py:200-318) on a fitted-model stand-in."""
+    import pandas as pd
+    from vimure_amd.batch import karnataka_tables
+    g = np.random.RandomState(0)
+    N = 9
+    X = np.zeros((1, N, N, N), np.uint8)
+    R = np.zeros((1, N, N, N), np.uint8)
+    rep = [0, 1, 2, 4, 5, 7]
+    for i in range(N):
+        for j in range(N):
+            for m in (i, j):
+                if m in rep and i != j:
+                    R[0, i, j, m] = 1
+                    X[0, i, j, m] = g.rand() < 0.3
+
+    class M:
+        pass
+    m = M()
+    m.num_realisations, m.max_iter, m.seed, m.maxL, m.G_exp_nu = 5, 101, 321, -12.5, 0.4
+    m.G_exp_lambda_f, m.G_exp_theta_f = np.array([[0.01, 1.3]]), g.rand(1, N)
+    m.rho_f = g.rand(1, N, N, 2)
+    m.rho_f /= m.rho_f.sum(-1)[..., None]
+    m.trace = pd.DataFrame({"realisation": [0], "seed": [3], "iter": [10], "elbo": [-1.0], "runtime": [0.1], "reached_convergence": [False]})
+    thr = 0.54 * m.G_exp_nu - 0.01
+    m.get_inferred_model = lambda method: (m.rho_f[..., 1] >= thr).astype(int)
+    t = karnataka_tables(m, X, R, "vilA", "money", 3, 1.5)
+    sumX = X.astype(int).sum(axis=3)
+    union, inter, Yv = sumX > 0, sumX == 2, m.rho_f[..., 1] >= thr
+    rows = []
+    for i in range(N):
+        for j in range(N):
+            r = {"village": "vilA", "layer": "money", "initial_seed": 3, "source": i, "target": j, "dyad_ID": f"{i}_{j}",
+                 "source_report": X[0, i, j, i] == 1, "target_report": X[0, i, j, j] == 1,
+                 "vimure_posterior_probability": m.rho_f[0, i, j, 1], "in_union": union[0, i, j], "in_intersection": inter[0, i, j],
+                 "in_vimure": Yv[0, i, j], "reciprocated_in_union": union[0, j, i], "reciprocated_in_intersection": inter[0, j, i],
+                 "reciprocated_in_vimure": Yv[0, j, i]}
+            if r["in_union"] or r["in_intersection"] or r["in_vimure"]:
+                rows.append(r)
+    ref = pd.DataFrame(rows)
+    assert list(t["edgelist"].columns) == list(ref.columns) and len(ref) > 0
+    pd.testing.assert_frame_equal(t["edgelist"].reset_index(drop=True), ref, check_dtype=False)
+    rel = t["reliability"]
+    assert list(rel.columns) == ["village", "layer", "initial_seed", "node", "theta", "lambda_theta", "is_node_reporter"]
+    assert rel["is_node_reporter"].tolist() == [n in rep for n in range(N)]
+    np.testing.assert_allclose(rel["lambda_theta"], 1.3 * m.G_exp_theta_f[0])
+    s = t["summary"]
+    assert list(s.columns) == ["running_time", "num_realisations", "max_iter", "initial_seed", "best_seed", "best_elbo", "eta_est",
+                               "lambda_k", "model", "village", "layer"] and len(s) == 1 and s["lambda_k"][0] == [0.01, 1.3]
+    assert list(t["trace"].columns[-3:]) == ["model", "village", "layer"]

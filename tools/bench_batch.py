@@ -11,22 +11,32 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vimure_amd.batch import fit_datasets  # noqa: E402
 from vimure_amd.synthetic import standard_sbm  # noqa: E402
+from vimure_amd.tensor import SparseTensor  # noqa: E402
 
 
 def main():
     warnings.simplefilter("ignore")
     sizes = [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "200,324,450,600").split(",")]
     n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    coo = (sys.argv[4] if len(sys.argv) > 4 else "coo") == "coo"
     data = {}
     for v, N in enumerate(sizes):
         net = standard_sbm(N=N, M=N, L=4, K=2, avg_degree=3.0, eta=0.3, seed=v, flag_self_reporter=True)
-        data[f"vil{v}"] = (net.X, net.R)
+        # as the reader delivers a village: coordinate containers (vimure_amd._io.read_from_edgelist), not dense tensors
+        data[f"vil{v}"] = (SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R)) if coo else (net.X, net.R)
         print(f"vil{v}: N={N} nnzX per layer ~{int((net.X > 0).sum() / 4)} nnzR per layer {int(net.R.sum() / 4)}", flush=True)
     t0 = time.perf_counter()
-    df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101)
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    procs = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    if procs:   # warm the worker processes up (interpreter start, imports, first kernel load): a pool serves many calls
+        fit_datasets({"w": data["vil0"]}, K=2, seeds=range(procs * 4), num_realisations=1, max_iter=11, workers=workers, processes=procs)
+        t0 = time.perf_counter()
+    df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=workers, processes=procs)
     dt = time.perf_counter() - t0
     n = len(df)
     print(df.groupby("dataset")[["seconds", "iters"]].mean())
+    from vimure_amd.batch import shutdown_pools
+    shutdown_pools()
     print(f"{n} fits (5 realisations each) in {dt:.2f} s -> {n / dt:.2f} fits/s; "
           f"extrapolated 75 villages x 4 layers x 10 seeds = 3000 fits: {3000 * dt / n / 60:.1f} min on one GPU "
           f"(reference: 3052 fits, mean 267.9 s each = 227 h single-process)")

@@ -21,6 +21,9 @@ _u8p = C.c_void_p  # host or device pointer
 SIGNATURES = {
     "vmr_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              _u8p, _u8p, C.c_int, C.c_double]),
+    "vmr_create_coo": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
     "vmr_destroy": (None, [C.c_void_p]),
     "vmr_last_error": (C.c_char_p, [C.c_void_p]),
     "vmr_data_stats": (C.c_int, [C.c_void_p, _dp, C.c_void_p]),
@@ -29,6 +32,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_int]),
     "vmr_step": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_elbo": (C.c_int, [C.c_void_p, _dp]),
+    "vmr_fit_loop": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vmr_sub_step": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_sweep_local": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_commit_nu": (C.c_int, [C.c_void_p, C.c_double]),

@@ -2,11 +2,20 @@
 experiment (notebooks/python/experiments/karnataka.py:126-318: per village, per layer separately (L = 1),
 10 seeds, `fit(X, R=R, K=2, seed=seed, num_realisations=5, max_iter=101)`, :188-191).
 
-One `CaviEngine` per (dataset, layer) holds the data on the GPU; all seeds of that layer reuse it.
+A small fit is bound by the latency of its dependent kernel launches (3 per sweep, 500 sweeps per fit), not by the
+GPU: one fit keeps a few per cent of an MI355X busy.  Units therefore run CONCURRENTLY: `workers` host threads, each
+driving its own `CaviEngine` (one handle = one HIP stream; handles are independent), so the kernels of several fits
+overlap on the device -- and, because the threads of one process still meet in the HIP runtime's launch path (8 threads:
+1.5x one thread), `processes` worker processes beside each other on the same GPU (4 processes x 2 threads: 3.6x).
+One engine per (dataset, layer) holds the data; all seeds of that unit reuse it.
 Across GPUs the units are sharded by `vimure_amd.multifit` (one process per GPU, ELBO gather at the end).
+`karnataka_tables` / `run_karnataka` produce the four result tables of the reference driver (karnataka.py:200-318).
 """
+import os
+import threading
 import time
 import warnings
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Sequence
 
 import numpy as np
@@ -14,50 +23,134 @@ import pandas as pd
 
 from .engine import CaviEngine
 from .model import VimureModel
-from .tensor import to_dense_u8
+from .tensor import is_sparse_like, layer_of, to_dense_u8
+
+DEFAULT_WORKERS = 8
+
+
+def _fit_unit(Xl, Rl, K, seeds, mutuality, device, name, keep, fit_kwargs):
+    """All seeds of one (dataset, layer) unit on one engine.  Returns (rows, models or best model)."""
+    rows, models = [], []
+    eps = float(fit_kwargs.get("EPS", 1e-12))
+    if is_sparse_like(Xl):   # coordinate lists go to the device as they are (vmr_create_coo)
+        if Rl is not None and not is_sparse_like(Rl):
+            from .tensor import SparseTensor
+            Rl = SparseTensor.fromarray(np.asarray(Rl) != 0)
+        eng = CaviEngine.from_coo(Xl.subs, Xl.vals, Xl.shape, R=None if Rl is None else Rl.subs, K=K, mutuality=mutuality,
+                                  eps=eps, device=device)
+    else:
+        eng = CaviEngine(Xl, Rl, K=K, mutuality=mutuality, eps=eps, device=device)
+    try:
+        for seed in seeds:
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = VimureModel(mutuality=mutuality)
+                m.fit(Xl, R=Rl, K=K, seed=int(seed), engine=eng, **fit_kwargs)
+            dt = time.perf_counter() - t0
+            rows.append({"layer": name, "seed": int(seed), "elbo": float(m.maxL),
+                         "iters": int(m.trace["iter"].max()) if len(m.trace) else 0,
+                         "converged": bool(m.trace["reached_convergence"].any()) if len(m.trace) else False,
+                         "seconds": dt, "nu": float(m.G_exp_nu_f)})
+            if keep == "all":
+                models.append((int(seed), m, dt))
+            elif keep == "best" and (not models or models[0][1].maxL < m.maxL):
+                models = [(int(seed), m, dt)]
+    finally:
+        eng.close()
+    return rows, models
+
+
+def _as_data(X, R):
+    """Coordinate containers stay as they are (when the report lists can hold them); everything else becomes dense uint8."""
+    if is_sparse_like(X) and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 63)):
+        return X, R
+    Xd = to_dense_u8(X, "X")
+    Rd = None if R is None else (to_dense_u8(R, "R") != 0).astype(np.uint8)
+    return Xd, Rd
+
+
+def _run_units(jobs, workers):
+    """jobs: callables; run on `workers` threads (1 = in this thread), results in job order."""
+    if workers <= 1 or len(jobs) <= 1:
+        return [j() for j in jobs]
+    with ThreadPoolExecutor(max_workers=min(workers, len(jobs)), thread_name_prefix="vmr-fit") as ex:
+        return [f.result() for f in [ex.submit(j) for j in jobs]]
+
+
+# ---- worker processes (several per GPU): top-level functions, so that the spawn start method can pickle them
+def _proc_init():
+    warnings.simplefilter("ignore")
+
+
+def _proc_units(payload):
+    """One chunk of units in a worker process: [(tag, Xl, Rl)] -> [(tag, rows)] (threads inside the process as usual)."""
+    chunk, K, seeds, mutuality, device, workers, fit_kwargs = payload
+    res = _run_units([lambda u=u: (u[0], _fit_unit(u[1], u[2], K, seeds, mutuality, device, u[0], None, fit_kwargs)[0]) for u in chunk],
+                     workers)
+    return res
+
+
+_pools = {}
+
+
+def _pool(processes):
+    """A persistent pool of worker processes (spawned: a forked child must not inherit an initialised GPU runtime)."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    if processes not in _pools:
+        _pools[processes] = ProcessPoolExecutor(max_workers=processes, mp_context=mp.get_context("spawn"), initializer=_proc_init)
+    return _pools[processes]
+
+
+def shutdown_pools():
+    for p in _pools.values():
+        p.shutdown()
+    _pools.clear()
+
+
+def _run_units_processes(units, K, seeds, mutuality, device, processes, workers, fit_kwargs):
+    """units: [(tag, Xl, Rl)] sorted longest first; dealt round-robin into 4 chunks per process (load balance), chunks run in the
+    pool.  Returns {tag: rows}."""
+    nchunk = max(1, min(len(units), 4 * processes))
+    chunks = [units[i::nchunk] for i in range(nchunk)]
+    futs = [_pool(processes).submit(_proc_units, (c, K, seeds, mutuality, device, workers, fit_kwargs)) for c in chunks]
+    out = {}
+    for f in futs:
+        for tag, rows in f.result():
+            out[tag] = rows
+    return out
 
 
 def fit_layers(X, R=None, K=2, seeds: Iterable[int] = range(10), layer_names: Sequence[str] = None, mutuality=True,
-               device=None, keep_posteriors=False, **fit_kwargs) -> pd.DataFrame:
+               device=None, keep_posteriors=False, workers=DEFAULT_WORKERS, **fit_kwargs) -> pd.DataFrame:
     """Fit every layer of one dataset separately for every seed.  Returns one row per (layer, seed):
     layer, seed, elbo (maxL), iters of the best realisation's last trace row, seconds, nu (= G_exp_nu_f),
-    and -- keep_posteriors -- the model object of the best seed per layer in `.attrs["best"]`."""
-    Xd = to_dense_u8(X, "X")
-    Rd = None if R is None else (to_dense_u8(R, "R") != 0).astype(np.uint8)
-    L = Xd.shape[0]
-    rows, best = [], {}
-    for l in range(L):
-        Xl = np.ascontiguousarray(Xd[l:l + 1])
-        Rl = None if Rd is None else np.ascontiguousarray(Rd[l:l + 1])
-        eng = CaviEngine(Xl, Rl, K=K, mutuality=mutuality, eps=float(fit_kwargs.get("EPS", 1e-12)), device=device)
-        try:
-            for seed in seeds:
-                t0 = time.perf_counter()
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    m = VimureModel(mutuality=mutuality)
-                    m.fit(Xl, R=Rl, K=K, seed=int(seed), engine=eng, **fit_kwargs)
-                dt = time.perf_counter() - t0
-                name = layer_names[l] if layer_names is not None else l
-                rows.append({"layer": name, "seed": int(seed), "elbo": float(m.maxL),
-                             "iters": int(m.trace["iter"].max()) if len(m.trace) else 0,
-                             "converged": bool(m.trace["reached_convergence"].any()) if len(m.trace) else False,
-                             "seconds": dt, "nu": float(m.G_exp_nu_f)})
-                if keep_posteriors and (name not in best or best[name].maxL < m.maxL):
-                    best[name] = m
-        finally:
-            eng.close()
-    out = pd.DataFrame(rows)
+    and -- keep_posteriors -- the model object of the best seed per layer in `.attrs["best"]`.
+    Layers run concurrently on up to `workers` threads (one engine and stream each)."""
+    Xd, Rd = _as_data(X, R)
+    seeds = list(seeds)
+    jobs = []
+    for l in range(int(Xd.shape[0])):
+        Xl = layer_of(Xd, l)
+        Rl = None if Rd is None else layer_of(Rd, l)
+        name = layer_names[l] if layer_names is not None else l
+        jobs.append(lambda Xl=Xl, Rl=Rl, name=name: _fit_unit(Xl, Rl, K, seeds, mutuality, device, name,
+                                                              "best" if keep_posteriors else None, fit_kwargs))
+    res = _run_units(jobs, workers)
+    out = pd.DataFrame([r for rows, _ in res for r in rows])
     if keep_posteriors:
-        out.attrs["best"] = best
+        out.attrs["best"] = {rows[0]["layer"]: models[0][1] for rows, models in res if models}
     return out
 
 
 def fit_datasets(datasets: Dict[str, tuple], K=2, seeds: Iterable[int] = range(10), dist=None, device=None,
-                 **fit_kwargs) -> pd.DataFrame:
+                 workers=DEFAULT_WORKERS, processes=0, **fit_kwargs) -> pd.DataFrame:
     """datasets: name -> (X, R, layer_names or None).  Units (dataset, layer) are sharded over the ranks of
-    `dist` (one process per GPU), all seeds of a unit run on the rank that holds its data; the per-fit rows
-    are gathered on every rank (RCCL / gloo all_gather of [unit, seed, elbo, iters, seconds, nu])."""
+    `dist` (one process per GPU), all seeds of a unit run on the rank that holds its data, units of a rank run
+    concurrently on `workers` threads -- in `processes` worker processes on the rank's GPU when processes > 0 (keep
+    processes x ranks per GPU small: a handful); the per-fit rows are gathered on every rank (RCCL / gloo all_gather of
+    [unit, seed, elbo, iters, seconds, nu])."""
     from .multifit import partition
     seeds = list(seeds)
     units = []
@@ -68,16 +161,30 @@ def fit_datasets(datasets: Dict[str, tuple], K=2, seeds: Iterable[int] = range(1
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     mine = partition([u[2] for u in units], world)[rank]
-    rows = []
-    for ui in mine:
+    mutuality = fit_kwargs.pop("mutuality", True)
+
+    def data_of(ui):
         name, l, _ = units[ui]
-        X, R, lnames = (tuple(datasets[name]) + (None,))[:3]
-        Xl = to_dense_u8(X, "X")[l:l + 1]
-        Rl = None if R is None else to_dense_u8(R, "R")[l:l + 1]
-        df = fit_layers(Xl, Rl, K=K, seeds=seeds, device=device, **fit_kwargs)
-        for _, r in df.iterrows():
-            rows.append([ui, r["seed"], r["elbo"], r["iters"], r["seconds"], r["nu"], float(r["converged"])])
-    local = np.asarray(rows, dtype=np.float64).reshape(-1, 7)
+        X, R, _ = (tuple(datasets[name]) + (None,))[:3]
+        if is_sparse_like(X):
+            Xd, Rd = _as_data(X, R)
+            return layer_of(Xd, l), (None if Rd is None else layer_of(Rd, l))
+        return _as_data(np.asarray(X)[l:l + 1], None if R is None else np.asarray(R)[l:l + 1])   # dense: slice first, convert the slice
+
+    def job(ui):
+        Xl, Rl = data_of(ui)
+        rows, _ = _fit_unit(Xl, Rl, K, seeds, mutuality, device, units[ui][1], None, fit_kwargs)
+        return rows
+    # longest units first: the tail of the schedule is short fits
+    order = sorted(mine, key=lambda ui: -units[ui][2])
+    if processes > 0:
+        by_tag = _run_units_processes([(ui,) + tuple(data_of(ui)) for ui in order], K, seeds, mutuality, device, processes, workers,
+                                      fit_kwargs)
+        res = [(ui, by_tag[ui]) for ui in order]
+    else:
+        res = list(zip(order, _run_units([lambda ui=ui: job(ui) for ui in order], workers)))
+    local = np.asarray([[ui, r["seed"], r["elbo"], r["iters"], r["seconds"], r["nu"], float(r["converged"])]
+                        for ui, rows in res for r in rows], dtype=np.float64).reshape(-1, 7)
     if world > 1:
         import torch
         tdev = "cpu" if dist.get_backend() == "gloo" else (f"cuda:{device}" if device is not None else "cuda")
@@ -92,3 +199,105 @@ def fit_datasets(datasets: Dict[str, tuple], K=2, seeds: Iterable[int] = range(1
     out["dataset"] = [units[int(u)][0] for u in out["unit"]]
     out["layer"] = [units[int(u)][1] for u in out["unit"]]
     return out.sort_values(["dataset", "layer", "seed"]).reset_index(drop=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's Karnataka result tables (karnataka.py:200-318), vectorised
+# ------------------------------------------------------------------------------------------------------------------
+KARNATAKA_FILES = {"summary": "vimure_model_summary.csv", "trace": "vimure_model_trace.csv",
+                   "edgelist": "vimure_model_edgelist.csv", "reliability": "vimure_model_reliability.csv"}
+
+
+def karnataka_tables(model, X, R, village, layer, seed, running_time) -> Dict[str, pd.DataFrame]:
+    """The four tables `karnataka.main` appends per (village, layer, seed) -- same columns, same row filter
+    (karnataka.py:200-318) -- from a fitted single-layer model and its data X, R ([1,N,N,N] dense uint8)."""
+    L, N = int(X.shape[0]), int(X.shape[1])
+    if is_sparse_like(X):   # per-tie sums and the ego's / alter's own reports from the coordinate lists
+        xl, xi, xj, xm = (np.asarray(a) for a in X.subs)
+        xv = np.asarray(X.vals)
+        sumX = np.zeros((L, N, N), np.int64)
+        np.add.at(sumX, (xl, xi, xj), xv)
+        src_rep = np.zeros((L, N, N), bool)
+        tgt_rep = np.zeros((L, N, N), bool)
+        es, et = (xm == xi) & (xv == 1), (xm == xj) & (xv == 1)
+        src_rep[xl[es], xi[es], xj[es]] = True
+        tgt_rep[xl[et], xi[et], xj[et]] = True
+        reporters = np.unique(np.asarray(R.subs[3]) if is_sparse_like(R) else np.nonzero(np.asarray(R))[3])
+    else:
+        X = np.asarray(X)
+        sumX = X.sum(axis=3)
+        ar = np.arange(N)
+        src_rep = X[:, ar[:, None], ar[None, :], ar[:, None]] == 1     # X[l,i,j,i]
+        tgt_rep = X[:, ar[:, None], ar[None, :], ar[None, :]] == 1     # X[l,i,j,j]
+        reporters = np.unique(np.asarray(R.subs[3]) if is_sparse_like(R) else np.nonzero(np.asarray(R))[3])
+    summary = pd.DataFrame({"running_time": running_time, "num_realisations": model.num_realisations, "max_iter": model.max_iter,
+                            "initial_seed": seed, "best_seed": model.seed, "best_elbo": model.maxL, "eta_est": model.G_exp_nu,
+                            "lambda_k": model.G_exp_lambda_f.tolist(), "model": "ViMuRe_T", "village": village, "layer": layer},
+                           index=list(range(len(model.G_exp_lambda_f.tolist()))))
+    trace = model.trace.copy()
+    trace["model"], trace["village"], trace["layer"] = "ViMuRe_T", village, layer
+    # edge list: union / intersection baselines and the thresholded posterior (utils.apply_rho_threshold)
+    union = sumX > 0
+    inter = sumX == 2
+    Yv = model.get_inferred_model(method="heuristic_threshold") == 1
+    ll, ii, jj = np.nonzero(union | inter | Yv)
+    rho1 = model.rho_f[..., 1]
+    edgelist = pd.DataFrame({
+        "village": village, "layer": layer, "initial_seed": seed, "source": ii, "target": jj,
+        "dyad_ID": [f"{i}_{j}" for i, j in zip(ii, jj)],
+        "source_report": src_rep[ll, ii, jj], "target_report": tgt_rep[ll, ii, jj],
+        "vimure_posterior_probability": rho1[ll, ii, jj],
+        "in_union": union[ll, ii, jj], "in_intersection": inter[ll, ii, jj], "in_vimure": Yv[ll, ii, jj],
+        "reciprocated_in_union": union[ll, jj, ii], "reciprocated_in_intersection": inter[ll, jj, ii],
+        "reciprocated_in_vimure": Yv[ll, jj, ii]})
+    lm, mm = np.meshgrid(np.arange(L), np.arange(N), indexing="ij")
+    reliability = pd.DataFrame({
+        "village": village, "layer": layer, "initial_seed": seed, "node": mm.ravel(),
+        "theta": model.G_exp_theta_f[lm.ravel(), mm.ravel()],
+        "lambda_theta": model.G_exp_lambda_f[lm.ravel(), 1] * model.G_exp_theta_f[lm.ravel(), mm.ravel()],
+        "is_node_reporter": np.isin(mm.ravel(), reporters)})
+    return {"summary": summary, "trace": trace, "edgelist": edgelist, "reliability": reliability}
+
+
+def run_karnataka(villages: Dict[str, tuple], seeds: Iterable[int] = range(1, 11), out_dir: str = None, K=2, mutuality=True,
+                  num_realisations=5, max_iter=101, device=None, workers=DEFAULT_WORKERS, **fit_kwargs) -> Dict[str, pd.DataFrame]:
+    """`karnataka.main` over many villages: villages = name -> (X [L,N,N,N], R, layer names); every layer is fitted on its own
+    (L = 1) for every seed with `fit(X, R=R, K=2, seed=seed, num_realisations=5, max_iter=101)` (karnataka.py:188-191).
+    With `out_dir` the four CSVs are appended as the reference does, and (village, layer, seed) rows already in the summary
+    file are skipped (its resume logic, karnataka.py:172-181).  Returns the four tables of this call."""
+    seeds = [int(s) for s in seeds]
+    done = set()
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        p = os.path.join(out_dir, KARNATAKA_FILES["summary"])
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            prev = pd.read_csv(p)
+            done = set(map(tuple, prev[["village", "layer", "initial_seed"]].drop_duplicates().values))
+    lock = threading.Lock()
+    acc = {k: [] for k in KARNATAKA_FILES}
+
+    def unit(village, l, lname, Xl, Rl):
+        todo = [s for s in seeds if (village, lname, s) not in done]
+        if not todo:
+            return
+        _, models = _fit_unit(Xl, Rl, K, todo, mutuality, device, lname, "all",
+                              dict(fit_kwargs, num_realisations=num_realisations, max_iter=max_iter))
+        for seed, m, dt in models:
+            tabs = karnataka_tables(m, Xl, Rl, village, lname, seed, dt)
+            with lock:
+                for k, df in tabs.items():
+                    acc[k].append(df)
+                    if out_dir is not None:
+                        path = os.path.join(out_dir, KARNATAKA_FILES[k])
+                        df.to_csv(path, mode="a", header=not os.path.exists(path) or os.path.getsize(path) == 0, index=False)
+    jobs = []
+    for village in sorted(villages):
+        X, R, lnames = (tuple(villages[village]) + (None,))[:3]
+        Xd, Rd = _as_data(X, R)
+        for l in range(int(Xd.shape[0])):
+            lname = lnames[l] if lnames is not None else l
+            jobs.append((float(Xd.shape[1]) ** 3, lambda village=village, l=l, lname=lname, Xl=layer_of(Xd, l),
+                         Rl=layer_of(Rd, l): unit(village, l, lname, Xl, Rl)))
+    jobs.sort(key=lambda j: -j[0])
+    _run_units([j for _, j in jobs], workers)
+    return {k: (pd.concat(v, ignore_index=True) if v else pd.DataFrame()) for k, v in acc.items()}

@@ -16,6 +16,7 @@
 //   k_fin_*        one workgroup per layer: gamma, phi, nu from H and A, the Gamma expectations
 //                  (digamma/log/exp), ELBO assembly -- no host round trip inside a sweep.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -25,6 +26,7 @@
 #include <vector>
 #include <utility>
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 
 #include "vimure_hip.h"
@@ -107,6 +109,12 @@ struct vmr_ctx {
   // state
   double *rho = nullptr, *logpr = nullptr;
   double* par = nullptr;       // parameter block, see P_* offsets
+  // steady-state sweeps as hipGraphs (vmr_step; env VMR_GRAPH=1).  Measured on the Karnataka-shaped batch (48 fits, 8 host
+  // threads): 22.3 fits/s with graphs against 22.9 without -- the dependent 10 us kernels of a sweep, not the launch calls,
+  // set a small fit's pace -- and a capture is invalidated when another host thread creates or destroys a handle meanwhile
+  // (hipMalloc / hipFree during capture), so the eager path is the default.
+  std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (sweeps in the graph, executable)
+  bool use_graphs = false;
   double *rho_snap = nullptr, *par_snap = nullptr;   // vmr_snapshot: the best realisation so far (model.py:925-942)
   bool have_snap = false;
   size_t par_doubles = 0;
@@ -1756,7 +1764,13 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
         for (int k = 0; k < K; ++k) ut[k * 64 + lane] = 0.0;
       }
-    } else put_rho(false);
+    } else {
+      put_rho(false);
+      if (!ELBO && a.do_hist == 1 && act && cls == 1u) {   // statistics of the CURRENT rho: all-ones mask rows are summed here too
+#pragma unroll
+        for (int k = 0; k < K; ++k) accF[k] += r[k];
+      }
+    }
     // next steps' loads
     ea1 = ea2; et1 = et2; ee1 = ee2;
     if (s + nw < s1_) {
@@ -1930,7 +1944,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
       }
     }
   }
-  if (UPDATE) {
+  if (UPDATE || (!ELBO && a.do_hist == 1)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       double v = block_sum_n(accF[k], red);
@@ -2456,6 +2470,8 @@ static int launch_hist(vmr_ctx* h) {
   const Geo& g = h->g;
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
+    HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));   // (the pass sums rho over all-ones mask rows)
+    h->f_valid = g.fuse_full != 0;
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     const SpShape sh = sp_shape(h, false, false, true);
     SpArgs a = sp_args(h, sh, 1);
@@ -2484,6 +2500,10 @@ static int launch_hist(vmr_ctx* h) {
 
 static int launch_gamma(vmr_ctx* h, bool with_phi) {
   const Geo& g = h->g;
+  if (h->sparse && !h->h_valid) {   // report lists: the statistics pass also sums rho over the all-ones mask rows (slotF)
+    int rc = launch_hist(h);
+    if (rc) return rc;
+  }
   // fork: the mask sums A = sum_ij R rho (memory-bound) run beside the statistics pass when one is needed
   hipStream_t ms = (h->serial || h->h_valid) ? h->stream : h->stream2;
   if (ms != h->stream) {
@@ -2657,310 +2677,668 @@ const char* vmr_version(void) { return VMR_VERSION; }
 
 const char* vmr_last_error(vmr_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality, const uint8_t* X,
-               const uint8_t* R, int data_on_device, double eps) {
-  if (!out) return fail(nullptr, VMR_EINVAL, "out is NULL");
-  *out = nullptr;
+}  // extern "C" (the create helpers are C++)
+
+// ------------------------------------------------------------------------------------------
+// vmr_create / vmr_create_coo
+// ------------------------------------------------------------------------------------------
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); return VMR_EHIP; } } while (0)
+
+// context, geometry, streams and the small per-dataset arrays
+static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, int N, int M, int K, int mutuality, double eps) {
   if (L < 1 || N < 1 || M < 1) return fail(nullptr, VMR_EINVAL, "L, N, M must be positive");
   if (K < 2 || K > KMAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 8]");
-  if (!X) return fail(nullptr, VMR_EINVAL, "X is NULL");
   int ndev = 0;
-  HIPCHK((vmr_ctx*)nullptr, hipGetDeviceCount(&ndev));
+  CK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(nullptr, VMR_EINVAL, "no such HIP device");
-  HIPCHK((vmr_ctx*)nullptr, hipSetDevice(device));
-  hipDeviceProp_t prop;
-  HIPCHK((vmr_ctx*)nullptr, hipGetDeviceProperties(&prop, device));
+  CK(hipSetDevice(device));
+  CK(hipGetDeviceProperties(prop, device));
   vmr_ctx* h = new vmr_ctx();
+  *out = h;
   h->device = device;
   Geo& g = h->g;
   g.L = L; g.N = N; g.M = M; g.K = K; g.mut = mutuality ? 1 : 0; g.eps = eps;
   std::string err;
-  if (choose_geo(g, prop.multiProcessorCount, err) != VMR_OK) { delete h; return fail(nullptr, VMR_EINVAL, err.c_str()); }
+  if (choose_geo(g, prop->multiProcessorCount, err) != VMR_OK) return fail(nullptr, VMR_EINVAL, err.c_str());
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
-#define CCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); vmr_destroy(h); return VMR_EHIP; } } while (0)
-  CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-  CCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  CCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  const size_t rows = (size_t)L * N * N;
-  const size_t raw = rows * M;
-  h->ncu = prop.multiProcessorCount;
+  CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  h->ncu = prop->multiProcessorCount;
   h->serial = getenv("VMR_SERIAL") != nullptr;
-  const size_t slack = (size_t)g.b * N + g.b;   // tile streams may read (never use) rows past the last tie
-  CCHK(hipMalloc(&h->X, (rows + slack) * g.Mp));
-  CCHK(hipMemsetAsync(h->X + rows * g.Mp, 0, slack * g.Mp, h->stream));
-  CCHK(hipMalloc(&h->Rb, (rows + slack) * g.W * 8));
-  CCHK(hipMemsetAsync(h->Rb + rows * g.W, 0, slack * g.W * 8, h->stream));
-  CCHK(hipMalloc(&h->cov, rows));
-  CCHK(hipMalloc(&h->rcls, rows));
-  CCHK(hipMalloc(&h->sumx, 8));
-  CCHK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
-  CCHK(hipMalloc(&h->xmax, 4));
-  CCHK(hipMemsetAsync(h->xmax, 0, 4, h->stream));
-  CCHK(hipMalloc(&h->npartial, 16));
-  CCHK(hipMemsetAsync(h->npartial, 0, 16, h->stream));
-  {
-    uint8_t* tmp = nullptr;
-    const uint8_t* src = X;
-    if (!data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, X, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
-    hipLaunchKernelGGL(k_pack_x, dim3(4096), dim3(256), 0, h->stream, src, h->X, rows, M, g.Mp);
-    CCHK(hipGetLastError());
-    CCHK(hipStreamSynchronize(h->stream));
-    if (tmp) CCHK(hipFree(tmp));
-    tmp = nullptr; src = R;
-    if (R && !data_on_device) { CCHK(hipMalloc(&tmp, raw)); CCHK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
-    hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
-    CCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->rcls, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
-    CCHK(hipGetLastError());
-    CCHK(hipStreamSynchronize(h->stream));
-    if (tmp) CCHK(hipFree(tmp));
-  }
-  CCHK(hipMalloc(&h->rho, rows * K * 8));
-  CCHK(hipMalloc(&h->logpr, rows * K * 8));
-  ParOff o = par_off(L, g.Mp, K);
+  h->use_graphs = getenv("VMR_GRAPH") != nullptr;   // off by default, see vmr_ctx::graphs
+  const size_t rows = (size_t)L * N * N;
+  CK(hipMalloc(&h->cov, rows));
+  CK(hipMalloc(&h->rcls, rows));
+  CK(hipMalloc(&h->sumx, 8));
+  CK(hipMemsetAsync(h->sumx, 0, 8, h->stream));
+  CK(hipMalloc(&h->xmax, 4));
+  CK(hipMemsetAsync(h->xmax, 0, 4, h->stream));
+  CK(hipMalloc(&h->npartial, 16));
+  CK(hipMemsetAsync(h->npartial, 0, 16, h->stream));
+  return VMR_OK;
+}
+
+// variational state and accumulation slots; reads back the data statistics (largest count, mask row classes)
+static int create_state(vmr_ctx* h, unsigned* xm_out) {
+  Geo& g = h->g;
+  const size_t rows = (size_t)g.L * g.N * g.N;
+  CK(hipMalloc(&h->rho, rows * g.K * 8));
+  CK(hipMalloc(&h->logpr, rows * g.K * 8));
+  ParOff o = par_off(g.L, g.Mp, g.K);
   h->par_doubles = o.total;
-  CCHK(hipMalloc(&h->par, o.total * 8));
-  CCHK(hipMemsetAsync(h->par, 0, o.total * 8, h->stream));
-  {
-    size_t nA = (size_t)L * NSLOT * g.W * 64 * K * 8;
-    CCHK(hipMalloc(&h->slotA, nA)); CCHK(hipMemsetAsync(h->slotA, 0, nA, h->stream));
-    CCHK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CCHK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
-    unsigned xm = 0;
-    CCHK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
-    CCHK(hipMemcpy(&h->n_partial, h->npartial, 8, hipMemcpyDeviceToHost));
-    g.fuse_full = 1;
-    CCHK(hipMalloc(&h->slotF, (size_t)L * NSLOT * K * 8));
-    CCHK(hipMemsetAsync(h->slotF, 0, (size_t)L * NSLOT * K * 8, h->stream));
-    g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
-    {
-      unsigned long long np2[2] = {0, 0};
-      CCHK(hipMemcpy(np2, h->npartial, 16, hipMemcpyDeviceToHost));
-      h->all_full = (np2[0] == 0 && np2[1] == 0) ? 1 : 0;
-    }
-    // ---- data format: report lists unless X is dense enough that 1 B per (tie, reporter) is less to read ----
-    {
-      const size_t T = (size_t)N * N;
-      const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
-      const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
-      const bool can_list = g.Mp <= 8192 && xm <= ENT_CMAX;   // 13-bit reporter field, 6-bit counts
-      if (!force_dense && can_list) {
-        unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
-        CCHK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
-        unsigned long long* nnz_dev = nullptr;
-        CCHK(hipMalloc(&nnz_dev, (size_t)L * 8));
-        CCHK(hipMemsetAsync(nnz_dev, 0, (size_t)L * 8, h->stream));
-        const unsigned cgrid = (unsigned)std::min<size_t>(8192, (T + 15) / 16);
-        for (int l = 0; l < L; ++l)
-          hipLaunchKernelGGL(k_sp_count, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             rp + (size_t)l * (T + 1), nnz_dev + l, g);
-        CCHK(hipGetLastError());
-        CCHK(hipStreamSynchronize(h->stream));   // the stream is non-blocking: a plain hipMemcpy does not wait for it
-        std::vector<unsigned long long> nl(L), eb(L);
-        CCHK(hipMemcpy(nl.data(), nnz_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
-        CCHK(hipFree(nnz_dev));
-        bool fits = true;
-        h->nnz = 0;
-        for (int l = 0; l < L; ++l) { eb[l] = h->nnz; h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
-        const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
-        h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
-        unsigned* bsum = nullptr;
-        if (h->sparse) {
-          const size_t n = T + 1, NS = (T + 63) / 64, n2 = 2 * NS + 1;
-          const unsigned nbs = (unsigned)((n + 2047) / 2048), nbs2 = (unsigned)((n2 + 2047) / 2048);
-          const unsigned sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
-          CCHK(hipMalloc(&bsum, (size_t)std::max(nbs, nbs2) * 4));
-          CCHK(hipMalloc(&h->rs, (size_t)L * n2 * 4));
-          // slot offsets of the steps (full rounds + rest, see k_sp_plan), then the per-tie offsets of the tie-major temp
-          for (int l = 0; l < L; ++l) {
-            unsigned* rpl = rp + (size_t)l * n;
-            unsigned* rsl = h->rs + (size_t)l * n2;
-            hipLaunchKernelGGL(k_sp_plan, dim3(sgrid), dim3(256), 0, h->stream, rpl, rsl, g);
-            hipLaunchKernelGGL(k_scan_local, dim3(nbs2), dim3(256), 0, h->stream, rsl, bsum, n2);
-            hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs2);
-            hipLaunchKernelGGL(k_scan_add, dim3(nbs2), dim3(256), 0, h->stream, rsl, bsum, n2);
-            hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
-            hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs);
-            hipLaunchKernelGGL(k_scan_add, dim3(nbs), dim3(256), 0, h->stream, rpl, bsum, n);
-          }
-          CCHK(hipGetLastError());
-          CCHK(hipStreamSynchronize(h->stream));
-          std::vector<unsigned> slots(L);   // slots per layer (reports + padding)
-          for (int l = 0; l < L; ++l)
-            CCHK(hipMemcpy(&slots[l], h->rs + (size_t)l * n2 + 2 * NS, 4, hipMemcpyDeviceToHost));
-          // (a layer whose slots overflow 32 bits cannot happen below 2^32 reports with at most 2x padding ... but check)
-          h->n_slots = 0;
-          bool ok_slots = true;
-          for (int l = 0; l < L; ++l) { eb[l] = h->n_slots; h->n_slots += slots[l]; ok_slots = ok_slots && (double)slots[l] >= (double)nl[l]; }
-          if (!ok_slots) { CCHK(hipFree(bsum)); CCHK(hipFree(rp)); vmr_destroy(h); return fail(nullptr, VMR_EINVAL, "more than 2^32 report slots in one layer"); }
-          CCHK(hipMalloc(&h->ebase, (size_t)L * 8));
-          CCHK(hipMemcpyAsync(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
-          CCHK(hipMalloc(&h->E, ((size_t)h->n_slots + 64) * 4));
-          CCHK(hipMalloc(&h->Qt, rows * 4));
-          CCHK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-          unsigned* etmp = nullptr;   // one layer's entries in tie-major order
-          unsigned long long nlmax = 0;
-          for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
-          CCHK(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
-          for (int l = 0; l < L; ++l) {
-            if (g.mut)
-              hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, rp + (size_t)l * n, etmp, h->Qt + (size_t)l * T, g);
-            else
-              hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                                 h->Rb + (size_t)l * T * g.W, rp + (size_t)l * n, etmp, h->Qt + (size_t)l * T, g);
-            hipLaunchKernelGGL(k_sp_round, dim3(sgrid), dim3(256), 0, h->stream, rp + (size_t)l * n, h->rs + (size_t)l * n2,
-                               etmp, h->E + eb[l], g);
-          }
-          CCHK(hipGetLastError());
-          CCHK(hipStreamSynchronize(h->stream));
-          CCHK(hipFree(etmp));
-          // ---- mask lists for partial rows that hold few reporters (self-reporter masks: two per row) ----
-          if (h->n_partial > 0 && !getenv("VMR_NO_RLISTS")) {
-            unsigned long long* tot_dev = nullptr;
-            unsigned* max_dev = nullptr;
-            CCHK(hipMalloc(&h->rq, (size_t)L * n * 4));
-            CCHK(hipMalloc(&tot_dev, (size_t)L * 8));
-            CCHK(hipMalloc(&max_dev, 4));
-            CCHK(hipMemsetAsync(tot_dev, 0, (size_t)L * 8, h->stream));
-            CCHK(hipMemsetAsync(max_dev, 0, 4, h->stream));
-            const unsigned rgrid = (unsigned)std::min<size_t>(4096, (T + 255) / 256);
-            for (int l = 0; l < L; ++l)
-              hipLaunchKernelGGL(k_rm_count, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
-                                 h->rcls + (size_t)l * T, h->rq + (size_t)l * n, tot_dev + l, max_dev, T, g.W);
-            CCHK(hipGetLastError());
-            CCHK(hipStreamSynchronize(h->stream));
-            std::vector<unsigned long long> rl_(L), rb_(L);
-            unsigned maxrow = 0;
-            CCHK(hipMemcpy(rl_.data(), tot_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
-            CCHK(hipMemcpy(&maxrow, max_dev, 4, hipMemcpyDeviceToHost));
-            CCHK(hipFree(tot_dev));
-            CCHK(hipFree(max_dev));
-            bool ok32 = true;
-            h->n_rm = 0;
-            for (int l = 0; l < L; ++l) { rb_[l] = h->n_rm; h->n_rm += rl_[l]; ok32 = ok32 && rl_[l] < 0xffffffffull; }
-            // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row)
-            const double list_bytes = 2.0 * (double)h->n_rm + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
-            if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024) {   // (A[Mp][K] of k_mask_lists lives in LDS)
-              for (int l = 0; l < L; ++l) {
-                unsigned* rql = h->rq + (size_t)l * n;
-                hipLaunchKernelGGL(k_scan_local, dim3(nbs), dim3(256), 0, h->stream, rql, bsum, n);
-                hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nbs);
-                hipLaunchKernelGGL(k_scan_add, dim3(nbs), dim3(256), 0, h->stream, rql, bsum, n);
-              }
-              CCHK(hipGetLastError());
-              CCHK(hipMalloc(&h->rbase, (size_t)L * 8));
-              CCHK(hipMemcpyAsync(h->rbase, rb_.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
-              CCHK(hipMalloc(&h->Rm, ((size_t)h->n_rm + 64) * 2));
-              for (int l = 0; l < L; ++l)
-                hipLaunchKernelGGL(k_rm_fill, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
-                                   h->rcls + (size_t)l * T, h->rq + (size_t)l * n, h->Rm + rb_[l], T, g.W);
-              CCHK(hipGetLastError());
-              CCHK(hipStreamSynchronize(h->stream));
-            } else {
-              CCHK(hipFree(h->rq));
-              h->rq = nullptr;
-              h->n_rm = 0;
-            }
-          }
-          CCHK(hipFree(bsum));
-          if (!getenv("VMR_KEEP_X")) { CCHK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
-        }
-        CCHK(hipFree(rp));
-      } else if (force_sparse) {
-        vmr_destroy(h);
-        return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192 and counts <= 63");
-      }
-    }
-    // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
-    g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
-    g.yt = 0;
-    g.two_pass = 0;
-    size_t need = 0;
-    if (h->sparse) {
-      // Report lists: both tables want the populous levels in LDS ([level][Mp][K] doubles each) beside 64 K doubles per
-      // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
-      // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
-      auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-      const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 8)));
-      auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {   // resident waves per CU: LDS and register limits
-        const size_t b = shmem_sp(g, tpb, yt, hc, upd, false, hist);
-        if (b > SP_LDS_MAX) return 0;
-        const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), (SP_WPE * 4) / nw);
-        return wgs * nw;
-      };
-      auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {   // most levels at >= min_waves per CU
-        for (int lv = want; lv >= 1; --lv) {
-          int bw = 0, bt = 256;
-          for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
-          if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
-        }
-        return false;
-      };
-      int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
-      const bool one = best(true, true, 16, lv1, t1);
-      if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
-      else {
-        g.two_pass = 1;
-        if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
-        if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
-        g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
-      }
-      // experiments: force the shape
-      if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
-      g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
-      g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
-      { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
-      for (int v = 0; v < 4; ++v) need = std::max(need, sp_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
-      CCHK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
-    } else {
-      if (shmem_rho(g, true, false) > 80000) {
-        g.two_pass = 1;
-        while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
-      }
-      need = std::max(shmem_rho(g, true, true), shmem_hist(g));
-    }
-    // per-reporter tables live in LDS (dense tiles: E[log theta], the mutuality weights c[m,k], G_theta for the ELBO:
-    // (K + 2) * 8 bytes per reporter).  160 KB per workgroup on gfx950.
-    if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
-      char msg[256];
-      snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
-               "reduce M or K", M, K, g.mut ? " and mutuality" : "", need, 160 * 1024);
-      vmr_destroy(h);
-      return fail(nullptr, VMR_EINVAL, msg);
-    }
-    CCHK(hipMalloc(&h->Hg, (size_t)L * NH * g.Y * g.Mp * K * 8));
-    CCHK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
+  CK(hipMalloc(&h->par, o.total * 8));
+  CK(hipMemsetAsync(h->par, 0, o.total * 8, h->stream));
+  const size_t nA = (size_t)g.L * NSLOT * g.W * 64 * g.K * 8;
+  CK(hipMalloc(&h->slotA, nA)); CK(hipMemsetAsync(h->slotA, 0, nA, h->stream));
+  CK(hipMalloc(&h->slotR, NSLOT * 4 * 8)); CK(hipMemsetAsync(h->slotR, 0, NSLOT * 4 * 8, h->stream));
+  g.fuse_full = 1;
+  CK(hipMalloc(&h->slotF, (size_t)g.L * NSLOT * g.K * 8));
+  CK(hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
+  CK(hipStreamSynchronize(h->stream));   // the stream is non-blocking: a plain hipMemcpy does not wait for it
+  unsigned xm = 0;
+  unsigned long long np2[2] = {0, 0};
+  CK(hipMemcpy(&xm, h->xmax, 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(np2, h->npartial, 16, hipMemcpyDeviceToHost));
+  h->n_partial = np2[0];
+  h->all_full = (np2[0] == 0 && np2[1] == 0) ? 1 : 0;
+  g.Y = g.mut ? (int)xm + 1 : 1;   // mirror counts 0..max(X)
+  *xm_out = xm;
+  return VMR_OK;
+}
+
+static int scan_u32(vmr_ctx* h, unsigned* a, unsigned* bsum, size_t n) {
+  const unsigned nb = (unsigned)((n + 2047) / 2048);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, h->stream, a, bsum, n);
+  hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nb);
+  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, h->stream, a, bsum, n);
+  CK(hipGetLastError());
+  return VMR_OK;
+}
+
+// Report lists from tie-major entries.  rp [L][T+1]: per-tie report counts (overwritten by their scan); nl[l]: reports of
+// layer l; fill(l, rp_l, etmp): writes layer l's entries tie-major (tie t's at rp_l[t], reporters ascending) into etmp --
+// or etmp_all already holds every layer's (layer l at offset sum of nl[<l]).
+template <class Fill>
+static int place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, Fill&& fill) {
+  Geo& g = h->g;
+  const int L = g.L;
+  const size_t T = (size_t)g.N * g.N, n = T + 1, NS = (T + 63) / 64, n2 = 2 * NS + 1, rows = (size_t)L * T;
+  const unsigned sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
+  unsigned* bsum = nullptr;
+  CK(hipMalloc(&bsum, (std::max(n, n2) + 2047) / 2048 * 4));
+  CK(hipMalloc(&h->rs, (size_t)L * n2 * 4));
+  // slot offsets of the steps (full rounds + rest, see k_sp_plan), then the per-tie offsets of the tie-major entries
+  for (int l = 0; l < L; ++l) {
+    unsigned* rpl = rp + (size_t)l * n;
+    unsigned* rsl = h->rs + (size_t)l * n2;
+    hipLaunchKernelGGL(k_sp_plan, dim3(sgrid), dim3(256), 0, h->stream, rpl, rsl, g);
+    int rc;
+    if ((rc = scan_u32(h, rsl, bsum, n2)) || (rc = scan_u32(h, rpl, bsum, n))) { (void)hipFree(bsum); return rc; }
   }
-  CCHK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
-  CCHK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
-  CCHK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
-  CCHK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  std::vector<unsigned> slots(L);   // slots per layer (reports + padding)
+  for (int l = 0; l < L; ++l) CK(hipMemcpy(&slots[l], h->rs + (size_t)l * n2 + 2 * NS, 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> eb(L);
+  h->n_slots = 0;
+  for (int l = 0; l < L; ++l) {
+    eb[l] = h->n_slots; h->n_slots += slots[l];
+    if ((double)slots[l] < (double)nl[l]) { (void)hipFree(bsum); return fail(nullptr, VMR_EINVAL, "more than 2^32 report slots in one layer"); }
+  }
+  CK(hipMalloc(&h->ebase, (size_t)L * 8));
+  CK(hipMemcpyAsync(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
+  CK(hipMalloc(&h->E, ((size_t)h->n_slots + 64) * 4));
+  if (!h->Qt) { CK(hipMalloc(&h->Qt, rows * 4)); CK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream)); }
+  unsigned* etmp = nullptr;   // one layer's entries in tie-major order
+  if (!etmp_all) {
+    unsigned long long nlmax = 0;
+    for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
+    CK(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
+  }
+  unsigned long long off = 0;
+  for (int l = 0; l < L; ++l) {
+    unsigned* src = etmp_all ? etmp_all + off : etmp;
+    if (!etmp_all) fill(l, rp + (size_t)l * n, etmp);
+    hipLaunchKernelGGL(k_sp_round, dim3(sgrid), dim3(256), 0, h->stream, rp + (size_t)l * n, h->rs + (size_t)l * n2, src, h->E + eb[l], g);
+    off += nl[l];
+  }
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));   // (eb lives on the host stack of the caller's frame: copied by now)
+  if (etmp) CK(hipFree(etmp));
+  CK(hipFree(bsum));
+  return VMR_OK;
+}
+
+// mask lists for partial rows that hold few reporters (self-reporter masks: two per row), from the bit-packed words
+static int mask_lists_from_words(vmr_ctx* h) {
+  Geo& g = h->g;
+  const int L = g.L, K = g.K;
+  const size_t T = (size_t)g.N * g.N, n = T + 1, rows = (size_t)L * T;
+  if (!(h->n_partial > 0) || getenv("VMR_NO_RLISTS")) return VMR_OK;
+  unsigned long long* tot_dev = nullptr;
+  unsigned* max_dev = nullptr;
+  unsigned* bsum = nullptr;
+  CK(hipMalloc(&h->rq, (size_t)L * n * 4));
+  CK(hipMalloc(&tot_dev, (size_t)L * 8));
+  CK(hipMalloc(&max_dev, 4));
+  CK(hipMalloc(&bsum, (n + 2047) / 2048 * 4));
+  CK(hipMemsetAsync(tot_dev, 0, (size_t)L * 8, h->stream));
+  CK(hipMemsetAsync(max_dev, 0, 4, h->stream));
+  const unsigned rgrid = (unsigned)std::min<size_t>(4096, (T + 255) / 256);
+  for (int l = 0; l < L; ++l)
+    hipLaunchKernelGGL(k_rm_count, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
+                       h->rcls + (size_t)l * T, h->rq + (size_t)l * n, tot_dev + l, max_dev, T, g.W);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  std::vector<unsigned long long> rl_(L), rb_(L);
+  unsigned maxrow = 0;
+  CK(hipMemcpy(rl_.data(), tot_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(&maxrow, max_dev, 4, hipMemcpyDeviceToHost));
+  CK(hipFree(tot_dev));
+  CK(hipFree(max_dev));
+  bool ok32 = true;
+  h->n_rm = 0;
+  for (int l = 0; l < L; ++l) { rb_[l] = h->n_rm; h->n_rm += rl_[l]; ok32 = ok32 && rl_[l] < 0xffffffffull; }
+  // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row)
+  const double list_bytes = 2.0 * (double)h->n_rm + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
+  if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024) {   // (A[Mp][K] of k_mask_lists lives in LDS)
+    for (int l = 0; l < L; ++l) { int rc = scan_u32(h, h->rq + (size_t)l * n, bsum, n); if (rc) return rc; }
+    CK(hipMalloc(&h->rbase, (size_t)L * 8));
+    CK(hipMemcpyAsync(h->rbase, rb_.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
+    CK(hipMalloc(&h->Rm, ((size_t)h->n_rm + 64) * 2));
+    for (int l = 0; l < L; ++l)
+      hipLaunchKernelGGL(k_rm_fill, dim3(rgrid), dim3(256), 0, h->stream, h->Rb + (size_t)l * T * g.W,
+                         h->rcls + (size_t)l * T, h->rq + (size_t)l * n, h->Rm + rb_[l], T, g.W);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(h->stream));
+  } else {
+    CK(hipFree(h->rq));
+    h->rq = nullptr;
+    h->n_rm = 0;
+  }
+  CK(hipFree(bsum));
+  return VMR_OK;
+}
+
+// LDS shapes, the statistics / factor tables, scratch; for report lists the count-mode launch (constants C[l][y][m])
+static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
+  Geo& g = h->g;
+  const int L = g.L, K = g.K;
+  // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
+  g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
+  g.yt = 0;
+  g.two_pass = 0;
+  size_t need = 0;
+  if (h->sparse) {
+    // Report lists: both tables want the populous levels in LDS ([level][Mp][K] doubles each) beside 64 K doubles per
+    // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
+    // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
+    auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 8)));
+    auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {   // resident waves per CU: LDS and register limits
+      const size_t b = shmem_sp(g, tpb, yt, hc, upd, false, hist);
+      if (b > SP_LDS_MAX) return 0;
+      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), (SP_WPE * 4) / nw);
+      return wgs * nw;
+    };
+    auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {   // most levels at >= min_waves per CU
+      for (int lv = want; lv >= 1; --lv) {
+        int bw = 0, bt = 256;
+        for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
+        if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
+      }
+      return false;
+    };
+    int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
+    const bool one = best(true, true, 16, lv1, t1);
+    if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
+    else {
+      g.two_pass = 1;
+      if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
+      if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
+      g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
+    }
+    // small datasets (a Karnataka village: 1640 steps): smaller workgroups, so that the steps spread over every CU --
+    // a sweep there is bound by the latency of its kernels, not by their throughput
+    {
+      const long long NS = ((long long)g.N * g.N + 63) / 64;
+      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb >>= 1;
+    }
+    // experiments: force the shape
+    if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
+    g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
+    g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
+    { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
+    for (int v = 0; v < 4; ++v) need = std::max(need, sp_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
+    CK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
+  } else {
+    if (shmem_rho(g, true, false) > 80000) {
+      g.two_pass = 1;
+      while (g.hc > 0 && shmem_hist(g) > 160000) --g.hc;
+    }
+    need = std::max(shmem_rho(g, true, true), shmem_hist(g));
+  }
+  // per-reporter tables live in LDS (dense tiles: E[log theta], the mutuality weights c[m,k], G_theta for the ELBO:
+  // (K + 2) * 8 bytes per reporter).  160 KB per workgroup on gfx950.
+  if (need > (size_t)prop.sharedMemPerBlock && need > 160 * 1024) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "M = %d reporters with K = %d%s needs %zu bytes of LDS per workgroup (limit %d): "
+             "reduce M or K", g.M, K, g.mut ? " and mutuality" : "", need, 160 * 1024);
+    return fail(nullptr, VMR_EINVAL, msg);
+  }
+  CK(hipMalloc(&h->Hg, (size_t)L * NH * g.Y * g.Mp * K * 8));
+  CK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
+  CK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
+  CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
+  CK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
+  CK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
   if (h->sparse) {
     // the constants C[l][y][m] = sum of the counts per (mirror count, reporter): one statistics launch in count mode
-    CCHK(hipMalloc(&h->Cg, (size_t)L * g.Y * g.Mp * 8));
+    CK(hipMalloc(&h->Cg, (size_t)L * g.Y * g.Mp * 8));
     const SpShape sh = sp_shape(h, false, false, true);
     SpArgs a = sp_args(h, sh, 2);
     int rc = VMR_OK;
     DISPATCH_K(g.K, rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb);
                if (rc == VMR_OK) hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
-    if (rc != VMR_OK) { g_create_err = h->err; vmr_destroy(h); return rc; }
-    CCHK(hipGetLastError());
+    if (rc != VMR_OK) { g_create_err = h->err; return rc; }
+    CK(hipGetLastError());
     const size_t nit = (size_t)L * g.Y * g.Mp;
     hipLaunchKernelGGL(k_take_counts, dim3((unsigned)std::min<size_t>(1024, (nit + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, h->Cg, g);
-    CCHK(hipGetLastError());
+    CK(hipGetLastError());
   }
-  CCHK(hipStreamSynchronize(h->stream));
-#undef CCHK
+  CK(hipStreamSynchronize(h->stream));
+  return VMR_OK;
+}
+
+static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* X, const uint8_t* R, int data_on_device) {
+  Geo& g = h->g;
+  const int L = g.L, N = g.N, M = g.M;
+  const size_t T = (size_t)N * N, rows = (size_t)L * T, raw = rows * M;
+  const size_t slack = (size_t)g.b * N + g.b;   // tile streams may read (never use) rows past the last tie
+  CK(hipMalloc(&h->X, (rows + slack) * g.Mp));
+  CK(hipMemsetAsync(h->X + rows * g.Mp, 0, slack * g.Mp, h->stream));
+  CK(hipMalloc(&h->Rb, (rows + slack) * g.W * 8));
+  CK(hipMemsetAsync(h->Rb + rows * g.W, 0, slack * g.W * 8, h->stream));
+  {
+    uint8_t* tmp = nullptr;
+    const uint8_t* src = X;
+    if (!data_on_device) { CK(hipMalloc(&tmp, raw)); CK(hipMemcpyAsync(tmp, X, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
+    hipLaunchKernelGGL(k_pack_x, dim3(4096), dim3(256), 0, h->stream, src, h->X, rows, M, g.Mp);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(h->stream));
+    if (tmp) CK(hipFree(tmp));
+    tmp = nullptr; src = R;
+    if (R && !data_on_device) { CK(hipMalloc(&tmp, raw)); CK(hipMemcpyAsync(tmp, R, raw, hipMemcpyHostToDevice, h->stream)); src = tmp; }
+    hipLaunchKernelGGL(k_pack_r, dim3(4096), dim3(256), 0, h->stream, src, h->Rb, rows, M, g.W);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(k_stats, dim3(2048), dim3(256), 0, h->stream, h->X, h->Rb, h->cov, h->rcls, h->sumx, h->xmax, h->npartial, rows, g.Mp, g.W, M);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(h->stream));
+    if (tmp) CK(hipFree(tmp));
+  }
+  unsigned xm = 0;
+  int rc = create_state(h, &xm);
+  if (rc) return rc;
+  // ---- data format: report lists unless X is dense enough that 1 B per (tie, reporter) is less to read ----
+  const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
+  const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
+  const bool can_list = g.Mp <= 8192 && xm <= ENT_CMAX;   // 13-bit reporter field, 6-bit counts
+  if (!force_dense && can_list) {
+    unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
+    CK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
+    unsigned long long* nnz_dev = nullptr;
+    CK(hipMalloc(&nnz_dev, (size_t)L * 8));
+    CK(hipMemsetAsync(nnz_dev, 0, (size_t)L * 8, h->stream));
+    const unsigned cgrid = (unsigned)std::min<size_t>(8192, (T + 15) / 16);
+    for (int l = 0; l < L; ++l)
+      hipLaunchKernelGGL(k_sp_count, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                         rp + (size_t)l * (T + 1), nnz_dev + l, g);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> nl(L);
+    CK(hipMemcpy(nl.data(), nnz_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
+    CK(hipFree(nnz_dev));
+    bool fits = true;
+    h->nnz = 0;
+    for (int l = 0; l < L; ++l) { h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
+    const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
+    h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
+    if (h->sparse) {
+      CK(hipMalloc(&h->Qt, rows * 4));
+      CK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
+      rc = place_entries(h, rp, nl, nullptr, [&](int l, const unsigned* rpl, unsigned* etmp) {
+        if (g.mut)
+          hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
+        else
+          hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
+      });
+      if (!rc) rc = mask_lists_from_words(h);
+      if (!rc && !getenv("VMR_KEEP_X")) { CK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
+    }
+    CK(hipFree(rp));
+    if (rc) return rc;
+  } else if (force_sparse) {
+    return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192 and counts <= 63");
+  }
+  return create_tail(h, prop);
+}
+
+extern "C" int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality, const uint8_t* X,
+                          const uint8_t* R, int data_on_device, double eps) {
+  if (!out) return fail(nullptr, VMR_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (L < 1 || N < 1 || M < 1) return fail(nullptr, VMR_EINVAL, "L, N, M must be positive");
+  if (K < 2 || K > KMAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 8]");
+  if (!X) return fail(nullptr, VMR_EINVAL, "X is NULL");
+  vmr_ctx* h = nullptr;
+  hipDeviceProp_t prop;
+  int rc = create_ctx(&h, &prop, device, L, N, M, K, mutuality, eps);
+  if (!rc) rc = create_dense(h, prop, X, R, data_on_device);
+  if (rc) { if (h) vmr_destroy(h); return rc; }
   *out = h;
   return VMR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// vmr_create_coo: coordinate lists (what the reference holds: sptensor subs / vals, model.py:136-171; the reader's output,
+// _io.py:132-295) straight to report lists -- no dense [L,N,N,M] tensor anywhere.  A Karnataka village layer is 624
+// reports against a 34 MB dense tensor; a layer of BASELINE config 5 is 5 GB of reports against 64 GB.
+// Reports and mask entries are sorted by (layer, tie, reporter) (one 64-bit radix sort each); sorted order IS the tie-major
+// order k_sp_round consumes, the mirror count and the mask bit of a report are binary searches in the sorted keys, and a
+// sparse mask becomes the mask lists directly.
+// ------------------------------------------------------------------------------------------
+#define COO_KEY(tie, m) (((unsigned long long)(tie) << 13) | (unsigned long long)(m))
+
+__global__ void k_coo_keys(const int32_t* __restrict__ sl, const int32_t* __restrict__ si, const int32_t* __restrict__ sj,
+                           const int32_t* __restrict__ sm, long long n, int L, int N, int M, unsigned long long* __restrict__ keys,
+                           int* bad) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int l = sl[e], i = si[e], j = sj[e], m = sm[e];
+    if (l < 0 || l >= L || i < 0 || i >= N || j < 0 || j >= N || m < 0 || m >= M) { atomicOr(bad, 1); keys[e] = ~0ull; continue; }
+    keys[e] = COO_KEY(((unsigned long long)l * N + i) * N + j, m);
+  }
+}
+// index of `key` in the sorted keys, or -1
+__device__ __forceinline__ long long coo_find(const unsigned long long* __restrict__ k, long long n, unsigned long long key) {
+  long long a = 0, b = n;
+  while (a < b) {
+    const long long c = a + ((b - a) >> 1);
+    if (k[c] < key) a = c + 1; else b = c;
+  }
+  return (a < n && k[a] == key) ? a : -1;
+}
+// per-tie counts of the sorted keys (cnt [L][T+1], layer-relative ties); duplicates flagged
+__global__ void k_coo_count(const unsigned long long* __restrict__ k, long long n, size_t T, unsigned* __restrict__ cnt, int* bad) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    if (e > 0 && k[e] == k[e - 1]) atomicOr(bad, 2);
+    const unsigned long long tie = k[e] >> 13, l = tie / T;
+    atomicAdd(&cnt[l * (T + 1) + (tie - l * T)], 1u);
+  }
+}
+// per tie: coverage, mask row class, statistics of the partial rows
+__global__ void k_coo_class(const unsigned* __restrict__ cx, const unsigned* __restrict__ cr /*null: all ones*/, size_t T, int L, int M,
+                            uint8_t* __restrict__ cov, uint8_t* __restrict__ rcls, unsigned long long* npartial, unsigned* maxrow) {
+  unsigned long long lpart = 0, lempty = 0;
+  unsigned mx = 0;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < (size_t)L * T; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = q / T, t = q - l * T;
+    const unsigned nX = cx[l * (T + 1) + t], nR = cr ? cr[l * (T + 1) + t] : (unsigned)M;
+    cov[q] = (nX > 0 && nR > 0) ? 1 : 0;
+    const unsigned c = nR == 0 ? 0u : (nR == (unsigned)M ? 1u : 2u);
+    rcls[q] = (uint8_t)c;
+    if (c == 2u) { ++lpart; mx = max(mx, nR); }
+    if (c == 0u) ++lempty;
+  }
+  if (lpart) atomicAdd(npartial, lpart);
+  if (lempty) atomicAdd(npartial + 1, lempty);
+  if (mx) atomicMax(maxrow, mx);
+}
+// the reports' entries in tie-major (= sorted) order, the mirror sums Qt, sum and maximum of the counts
+template <bool MUT>
+__global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const unsigned* __restrict__ vx, long long nx,
+                              const unsigned long long* __restrict__ kr, long long nr /* < 0: all ones */, int N, int Mp,
+                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad) {
+  unsigned long long s = 0;
+  unsigned mx = 0;
+  const unsigned long long T = (unsigned long long)N * N;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long key = kx[e], tie = key >> 13, l = tie / T, t = tie - l * T, i = t / N, j = t - i * N;
+    const unsigned m = (unsigned)(key & 0x1fffu), x = vx[e];
+    if (x == 0u || x > ENT_CMAX) { atomicOr(bad, 4); continue; }
+    s += x; mx = max(mx, x);
+    const unsigned long long tm = l * T + j * N + i;
+    unsigned y = 0;
+    if (MUT) {
+      const long long f = coo_find(kx, nx, COO_KEY(tm, m));
+      y = f >= 0 ? vx[f] : 0u;
+      if (nr < 0 || coo_find(kr, nr, COO_KEY(tm, m)) >= 0) atomicAdd(&Qt[tm], x);   // R[mirror, m] X[this, m]
+    }
+    const unsigned inr = (nr < 0 || coo_find(kr, nr, key) >= 0) ? 1u : 0u;
+    etmp[e] = (y * (unsigned)Mp + m) | (inr << 19) | ((unsigned)(t & 63) << 20) | (x << 26);
+  }
+  if (s) atomicAdd(sumx, s);
+  if (mx) atomicMax(xmax, mx);
+}
+// first sorted key of every layer (starts[L] = n)
+__global__ void k_coo_layer_starts(const unsigned long long* __restrict__ k, long long n, unsigned long long T, int L, unsigned long long* starts) {
+  for (int l = threadIdx.x; l <= L; l += blockDim.x) {
+    const unsigned long long k0 = ((unsigned long long)l * T) << 13;
+    long long a = 0, b = n;
+    while (a < b) { const long long c = a + ((b - a) >> 1); if (k[c] < k0) a = c + 1; else b = c; }
+    starts[l] = (unsigned long long)a;
+  }
+}
+// listed counts of the partial rows only
+__global__ void k_coo_listed(const unsigned* __restrict__ cr, const uint8_t* __restrict__ rcls, size_t T, int L, unsigned* __restrict__ rq) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < (size_t)L * (T + 1); q += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = q / (T + 1), t = q - l * (T + 1);
+    rq[q] = (t < T && rcls[l * T + t] == 2) ? cr[q] : 0u;
+  }
+}
+// reporters of the partial rows into the mask lists (rq scanned per layer; rbase: layer offsets)
+__global__ void k_coo_rm(const unsigned long long* __restrict__ kr, long long nr, size_t T, const uint8_t* __restrict__ rcls,
+                         const unsigned* __restrict__ rq, const unsigned long long* __restrict__ rbase, unsigned short* __restrict__ Rm) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nr; e += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long tie = kr[e] >> 13, l = tie / T, t = tie - l * T;
+    if (rcls[tie] != 2) continue;
+    long long a = 0, b = e;   // first entry of this tie: lower bound of tie << 13 in [0, e]
+    const unsigned long long k0 = tie << 13;
+    while (a < b) { const long long c = a + ((b - a) >> 1); if (kr[c] < k0) a = c + 1; else b = c; }
+    Rm[rbase[l] + rq[l * (T + 1) + t] + (unsigned long long)(e - a)] = (unsigned short)(kr[e] & 0x1fffu);
+  }
+}
+// a mask whose partial rows are long: bit-packed words as in the dense path
+__global__ void k_coo_rbits(const unsigned long long* __restrict__ kr, long long nr, int W, unsigned long long* __restrict__ Rb) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nr; e += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long tie = kr[e] >> 13;
+    const unsigned m = (unsigned)(kr[e] & 0x1fffu);
+    atomicOr(&Rb[tie * W + (m >> 6)], 1ull << (m & 63));
+  }
+}
+
+// sorted keys (and values) of a coordinate list on the device; *k_out, *v_out are hipMalloc'ed
+static int coo_sorted(vmr_ctx* h, long long n, const int32_t* sl, const int32_t* si, const int32_t* sj, const int32_t* sm,
+                      const int32_t* sv, int on_device, unsigned long long** k_out, unsigned** v_out, int* bad_dev) {
+  const Geo& g = h->g;
+  *k_out = nullptr;
+  if (v_out) *v_out = nullptr;
+  const size_t nn = (size_t)std::max<long long>(n, 1);
+  const int32_t* src[5] = {sl, si, sj, sm, sv};
+  int32_t* tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int ncol = sv ? 5 : 4;
+  if (!on_device) {
+    for (int c = 0; c < ncol; ++c) {
+      CK(hipMalloc(&tmp[c], nn * 4));
+      if (n > 0) CK(hipMemcpyAsync(tmp[c], src[c], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+      src[c] = tmp[c];
+    }
+  }
+  unsigned long long *k0 = nullptr, *k1 = nullptr;
+  unsigned* v1 = nullptr;
+  CK(hipMalloc(&k0, nn * 8));
+  CK(hipMalloc(&k1, nn * 8));
+  if (sv) CK(hipMalloc(&v1, nn * 4));
+  const unsigned grid = (unsigned)std::min<long long>(4096, (n + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_coo_keys, dim3(grid), dim3(256), 0, h->stream, src[0], src[1], src[2], src[3], n, g.L, g.N, g.M, k0, bad_dev);
+  CK(hipGetLastError());
+  int bits = 13;
+  { unsigned long long ties = (unsigned long long)g.L * g.N * g.N; while ((1ull << (bits - 13)) < ties && bits < 64) ++bits; }
+  size_t tb = 0;
+  void* td = nullptr;
+  if (n > 0) {
+    if (sv) CK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k1, reinterpret_cast<const unsigned*>(src[4]), v1, (int)n, 0, bits, h->stream));
+    else CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k0, k1, (int)n, 0, bits, h->stream));
+    CK(hipMalloc(&td, tb ? tb : 8));
+    if (sv) CK(hipcub::DeviceRadixSort::SortPairs(td, tb, k0, k1, reinterpret_cast<const unsigned*>(src[4]), v1, (int)n, 0, bits, h->stream));
+    else CK(hipcub::DeviceRadixSort::SortKeys(td, tb, k0, k1, (int)n, 0, bits, h->stream));
+  }
+  CK(hipStreamSynchronize(h->stream));
+  if (td) CK(hipFree(td));
+  CK(hipFree(k0));
+  for (int c = 0; c < ncol; ++c) if (tmp[c]) CK(hipFree(tmp[c]));
+  *k_out = k1;
+  if (v_out) *v_out = v1;
+  return VMR_OK;
+}
+
+static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, const int32_t* xl, const int32_t* xi, const int32_t* xj,
+                      const int32_t* xm, const int32_t* xv, long long nr, const int32_t* rl, const int32_t* ri, const int32_t* rj,
+                      const int32_t* rm, int on_device) {
+  Geo& g = h->g;
+  const int L = g.L, N = g.N, M = g.M, K = g.K;
+  const size_t T = (size_t)N * N, rows = (size_t)L * T, n1 = (size_t)L * (T + 1);
+  if (g.Mp > 8192) return fail(nullptr, VMR_EINVAL, "report lists hold 13-bit reporter indices: M <= 8192 (use vmr_create for wider tensors)");
+  if (nx >= 0x7fffffffll || nr >= 0x7fffffffll) return fail(nullptr, VMR_EINVAL, "more than 2^31 coordinates in one call");
+  int* bad_dev = nullptr;
+  CK(hipMalloc(&bad_dev, 4));
+  CK(hipMemsetAsync(bad_dev, 0, 4, h->stream));
+  unsigned long long *kx = nullptr, *kr = nullptr;
+  unsigned* vx = nullptr;
+  int rc = coo_sorted(h, nx, xl, xi, xj, xm, xv, on_device, &kx, &vx, bad_dev);
+  if (!rc && nr >= 0) rc = coo_sorted(h, nr, rl, ri, rj, rm, nullptr, on_device, &kr, nullptr, bad_dev);
+  unsigned *cx = nullptr, *cr = nullptr, *etmp = nullptr, *maxrow_dev = nullptr;
+  auto cleanup = [&]() { void* p[] = {bad_dev, kx, kr, vx, cx, cr, etmp, maxrow_dev}; for (void* q : p) if (q) (void)hipFree(q); };
+  if (rc) { cleanup(); return rc; }
+  {   // subscripts outside the tensor must not reach the kernels below (their keys index the per-tie arrays)
+    int bad0 = 0;
+    hipError_t e0 = hipMemcpy(&bad0, bad_dev, 4, hipMemcpyDeviceToHost);   // (coo_sorted synchronised the stream)
+    if (e0 != hipSuccess) { g_create_err = hipGetErrorString(e0); cleanup(); return VMR_EHIP; }
+    if (bad0 & 1) { cleanup(); return fail(nullptr, VMR_EINVAL, "a subscript lies outside (L, N, N, M)"); }
+  }
+#define CKC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); cleanup(); return VMR_EHIP; } } while (0)
+  CKC(hipMalloc(&cx, n1 * 4));
+  CKC(hipMemsetAsync(cx, 0, n1 * 4, h->stream));
+  const unsigned gx = (unsigned)std::min<long long>(8192, (nx + 255) / 256 + 1), gr = (unsigned)std::min<long long>(8192, (std::max<long long>(nr, 0) + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_coo_count, dim3(gx), dim3(256), 0, h->stream, kx, nx, T, cx, bad_dev);
+  if (nr >= 0) {
+    CKC(hipMalloc(&cr, n1 * 4));
+    CKC(hipMemsetAsync(cr, 0, n1 * 4, h->stream));
+    hipLaunchKernelGGL(k_coo_count, dim3(gr), dim3(256), 0, h->stream, kr, nr, T, cr, bad_dev);
+  }
+  CKC(hipMalloc(&maxrow_dev, 4));
+  CKC(hipMemsetAsync(maxrow_dev, 0, 4, h->stream));
+  hipLaunchKernelGGL(k_coo_class, dim3((unsigned)std::min<size_t>(4096, (rows + 255) / 256)), dim3(256), 0, h->stream, cx, cr, T, L, M,
+                     h->cov, h->rcls, h->npartial, maxrow_dev);
+  CKC(hipMalloc(&etmp, ((size_t)nx + 64) * 4));
+  CKC(hipMalloc(&h->Qt, rows * 4));
+  CKC(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
+  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
+  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
+  CKC(hipGetLastError());
+  CKC(hipStreamSynchronize(h->stream));
+  int bad = 0;
+  unsigned maxrow = 0;
+  CKC(hipMemcpy(&bad, bad_dev, 4, hipMemcpyDeviceToHost));
+  CKC(hipMemcpy(&maxrow, maxrow_dev, 4, hipMemcpyDeviceToHost));
+  if (bad) {
+    cleanup();
+    return fail(nullptr, VMR_EINVAL, (bad & 1) ? "a subscript lies outside (L, N, N, M)"
+                                   : (bad & 2) ? "duplicate (l, i, j, m) subscripts"
+                                               : "counts must lie in [1, 63] for the report lists (use vmr_create for larger counts)");
+  }
+  unsigned xmv = 0;
+  if ((rc = create_state(h, &xmv))) { cleanup(); return rc; }
+  h->sparse = 1;
+  h->nnz = (unsigned long long)nx;
+  // reports per layer: where each layer starts in the sorted keys
+  std::vector<unsigned long long> nl(L, 0);
+  {
+    unsigned long long* starts = nullptr;
+    CKC(hipMalloc(&starts, (size_t)(L + 1) * 8));
+    hipLaunchKernelGGL(k_coo_layer_starts, dim3(1), dim3(64), 0, h->stream, kx, nx, (unsigned long long)T, L, starts);
+    std::vector<unsigned long long> st(L + 1);
+    hipError_t e1 = hipMemcpyAsync(st.data(), starts, (size_t)(L + 1) * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
+    (void)hipFree(starts);
+    CKC(e1);
+    for (int l = 0; l < L; ++l) nl[l] = st[l + 1] - st[l];
+  }
+  rc = place_entries(h, cx, nl, etmp, [](int, const unsigned*, unsigned*) {});
+  if (rc) { cleanup(); return rc; }
+  // the mask: all ones needs nothing; partial rows become mask lists when they are short, bit-packed words otherwise
+  if (nr >= 0 && h->n_partial > 0) {
+    const double list_bytes = 2.0 * (double)nr + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
+    const bool lists = !getenv("VMR_NO_RLISTS") && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024;
+    if (lists) {
+      unsigned* bs = nullptr;
+      CKC(hipMalloc(&h->rq, n1 * 4));
+      CKC(hipMalloc(&bs, ((T + 1) + 2047) / 2048 * 4));
+      hipLaunchKernelGGL(k_coo_listed, dim3((unsigned)std::min<size_t>(4096, (n1 + 255) / 256)), dim3(256), 0, h->stream, cr, h->rcls, T, L, h->rq);
+      std::vector<unsigned long long> rb_(L);
+      h->n_rm = 0;
+      for (int l = 0; l < L; ++l) {
+        if ((rc = scan_u32(h, h->rq + (size_t)l * (T + 1), bs, T + 1))) { (void)hipFree(bs); cleanup(); return rc; }
+        unsigned tot = 0;
+        CKC(hipStreamSynchronize(h->stream));
+        CKC(hipMemcpy(&tot, h->rq + (size_t)l * (T + 1) + T, 4, hipMemcpyDeviceToHost));
+        rb_[l] = h->n_rm; h->n_rm += tot;
+      }
+      CKC(hipFree(bs));
+      CKC(hipMalloc(&h->rbase, (size_t)L * 8));
+      CKC(hipMemcpy(h->rbase, rb_.data(), (size_t)L * 8, hipMemcpyHostToDevice));
+      CKC(hipMalloc(&h->Rm, ((size_t)h->n_rm + 64) * 2));
+      hipLaunchKernelGGL(k_coo_rm, dim3(gr), dim3(256), 0, h->stream, kr, nr, T, h->rcls, h->rq, h->rbase, h->Rm);
+      CKC(hipGetLastError());
+    } else {
+      CKC(hipMalloc(&h->Rb, rows * g.W * 8));
+      CKC(hipMemsetAsync(h->Rb, 0, rows * g.W * 8, h->stream));
+      hipLaunchKernelGGL(k_coo_rbits, dim3(gr), dim3(256), 0, h->stream, kr, nr, g.W, reinterpret_cast<unsigned long long*>(h->Rb));
+      CKC(hipGetLastError());
+    }
+  }
+  CKC(hipStreamSynchronize(h->stream));
+#undef CKC
+  cleanup();
+  return create_tail(h, prop);
+}
+
+extern "C" int vmr_create_coo(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality, int64_t nx, const int32_t* xl,
+                              const int32_t* xi, const int32_t* xj, const int32_t* xm, const int32_t* xv, int64_t nr, const int32_t* rl,
+                              const int32_t* ri, const int32_t* rj, const int32_t* rm, int data_on_device, double eps) {
+  if (!out) return fail(nullptr, VMR_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (nx < 0 || (nx > 0 && (!xl || !xi || !xj || !xm || !xv))) return fail(nullptr, VMR_EINVAL, "X coordinate arrays missing");
+  if (nr > 0 && (!rl || !ri || !rj || !rm)) return fail(nullptr, VMR_EINVAL, "R coordinate arrays missing");
+  vmr_ctx* h = nullptr;
+  hipDeviceProp_t prop;
+  int rc = create_ctx(&h, &prop, device, L, N, M, K, mutuality, eps);
+  if (!rc) rc = create_coo(h, prop, nx, xl, xi, xj, xm, xv, nr, rl, ri, rj, rm, data_on_device);
+  if (rc) { if (h) vmr_destroy(h); return rc; }
+  *out = h;
+  return VMR_OK;
+}
+
+extern "C" {
 
 void vmr_destroy(vmr_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
   void* ptrs[] = {h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
@@ -3064,11 +3442,37 @@ static int read_elbo(vmr_ctx* h, double* out) {
 }
 
 static int sweep(vmr_ctx* h, int mode) {
-  // (hipGraph replay of the sweep was tried: 58 vs 63 us per sweep on a 100-node network -- the small-fit
-  //  regime is bound by the kernels' own fixed costs, not by launch calls; kept eager.)
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;   // gamma and phi are finished by one kernel
   return launch_rho(h, mode, true);
+}
+
+// After a committed sweep the handle is in a fixed point of its bookkeeping: the next sweep is the same three or four
+// launches with the same arguments.  Such sweeps are captured once (per count n) and replayed as one graph launch.
+static bool sweep_steady(const vmr_ctx* h) {
+  return h->have_state && h->h_valid && h->h_reduced && !h->h_zero && h->f_valid == (h->g.fuse_full != 0) && !h->prof;
+}
+static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
+  for (auto& e : h->graphs) if (e.first == n) { *out = e.second; return VMR_OK; }
+  hipGraph_t gr = nullptr;
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = VMR_OK;
+  for (int i = 0; i < n && rc == VMR_OK; ++i) rc = sweep(h, 0);
+  hipError_t e = hipStreamEndCapture(h->stream, &gr);
+  if (rc != VMR_OK || e != hipSuccess || !gr) {
+    if (gr) (void)hipGraphDestroy(gr);
+    (void)hipGetLastError();
+    h->use_graphs = false;   // eager from now on
+    if (rc == VMR_OK) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); rc = VMR_EHIP; }
+    return rc;
+  }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(gr);
+  if (e != hipSuccess) { (void)hipGetLastError(); h->use_graphs = false; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return VMR_EHIP; }
+  h->graphs.push_back({n, ex});
+  *out = ex;
+  return VMR_OK;
 }
 
 int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
@@ -3077,7 +3481,19 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
   if (n_iters < 0) return fail(h, VMR_EINVAL, "n_iters < 0");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
-  for (int it = 0; it < n_iters; ++it) {
+  int it = 0;
+  const int plain = elbo_out ? n_iters - 1 : n_iters;   // sweeps without an ELBO
+  if (h->use_graphs && plain >= 2) {
+    if (!sweep_steady(h)) { if ((rc = sweep(h, 0))) return rc; it = 1; }
+    while (h->use_graphs && sweep_steady(h) && plain - it >= 2) {
+      const int n = (plain - it >= 9) ? 9 : (plain - it);   // the fit loop asks for 9 between two ELBO checks (model.py:1036)
+      hipGraphExec_t ex = nullptr;
+      if (graph_for(h, n, &ex) != VMR_OK) break;   // capture failed: the eager loop below takes over
+      HIPCHK(h, hipGraphLaunch(ex, h->stream));
+      it += n;
+    }
+  }
+  for (; it < n_iters; ++it) {
     bool last = (it == n_iters - 1) && elbo_out;
     if ((rc = sweep(h, last ? 1 : 0))) return rc;
   }
@@ -3085,6 +3501,40 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
     if (n_iters == 0) return vmr_elbo(h, elbo_out);
     return read_elbo(h, elbo_out);
   }
+  return VMR_OK;
+}
+
+// the convergence loop of `fit` for one realisation (model.py:405-426, 1021-1056), without a host-language round trip
+// per iteration: one call per realisation, so several fits driven from host threads do not queue for an interpreter lock
+int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter, double* row_elbo,
+                 double* row_runtime, int* row_reached, double* elbo_out, int* iters_out, int* converged_out) {
+  if (!h || !n_rows || !elbo_out || !iters_out || !converged_out) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_fit_loop");
+  if (cap > 0 && (!row_iter || !row_elbo || !row_runtime || !row_reached)) return fail(h, VMR_EINVAL, "trace arrays missing");
+  int coincide = 0, it = 1, reached = 0, rows = 0, rc;
+  double elbo = -1e10;   // INF of the reference (model.py:24)
+  while (!reached && it <= max_iter) {
+    // the ELBO is evaluated at iteration 1, every 10th and the last (model.py:1036-1039); the sweeps in between are queued at once
+    const int nxt = (it == 1 || it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
+    if (nxt > it) {
+      if ((rc = vmr_step(h, nxt - it, nullptr))) return rc;
+      it = nxt;
+      HIPCHK(h, hipStreamSynchronize(h->stream));   // so that the runtime below is this iteration's sweep, as in the reference
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const double old = elbo;
+    if ((rc = vmr_step(h, 1, &elbo))) return rc;
+    const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    coincide = (fabs(elbo - old) < tol) ? coincide + 1 : 0;
+    if (coincide > decision) reached = 1;
+    ++it;
+    if ((it - 1) % 10 == 0 && rows < cap) {
+      row_iter[rows] = it - 1; row_elbo[rows] = elbo; row_runtime[rows] = runtime; row_reached[rows] = reached;
+      ++rows;
+    }
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *n_rows = rows; *elbo_out = elbo; *iters_out = it - 1; *converged_out = reached;
   return VMR_OK;
 }
 

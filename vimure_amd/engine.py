@@ -77,6 +77,57 @@ class CaviEngine:
             raise (ValueError if rc == _lib.VMR_EINVAL else EngineError)(msg)
         self._keep = (X, R)
 
+    @classmethod
+    def from_coo(cls, subs, vals, shape, R=None, K=2, mutuality=True, eps=1e-12, device=None):
+        """Dataset from coordinate lists -- the reference's own containers (`X.subs`, `X.vals`, `R.subs`; reference
+        model.py:136-171) -- without a dense [L,N,N,M] tensor on the host or the device (vmr_create_coo).
+        subs: 4 index arrays (l, i, j, m); vals: counts in [1, 63]; R: None (every reporter may report on every tie) or 4
+        index arrays of the mask's non-zeros; NumPy arrays or torch GPU tensors (int32 / int64)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self._staging = []
+        self.lib = _lib.load()
+        on_dev = _is_torch(vals)
+        L, N, N2, M = (int(s) for s in shape)
+        if N != N2:
+            raise ValueError("X must have shape (L, N, N, M)")
+
+        def cols(arrs):
+            if on_dev:
+                import torch
+                out = [a.to(torch.int32).contiguous() for a in arrs]
+                return out, [a.data_ptr() for a in out]
+            out = [np.ascontiguousarray(a, dtype=np.int32) for a in arrs]
+            return out, [a.ctypes.data for a in out]
+        if len(subs) != 4:
+            raise ValueError("subs must be the 4 index arrays (l, i, j, m)")
+        xk, xp = cols(list(subs) + [vals])
+        nx = int(xk[0].shape[0])
+        if any(int(a.shape[0]) != nx for a in xk):
+            raise ValueError("Subscripts and values must be of equal length")
+        if R is None:
+            rk, rp, nr = [], [None] * 4, -1
+        else:
+            if len(R) != 4:
+                raise ValueError("R must be the 4 index arrays (l, i, j, m) of the mask's non-zeros")
+            rk, rp = cols(list(R))
+            nr = int(rk[0].shape[0])
+        if device is None:
+            device = (vals.device.index or 0) if on_dev else 0
+        if on_dev:
+            import torch
+            torch.cuda.synchronize(vals.device)
+        self.L, self.N, self.M = L, N, M
+        self.K, self.mutuality, self.device = int(K), bool(mutuality), int(device)
+        rc = self.lib.vmr_create_coo(C.byref(self._h), self.device, L, N, M, self.K, int(self.mutuality), nx, *xp, nr, *rp,
+                                     int(on_dev), float(eps))
+        if rc != 0:
+            msg = self.lib.vmr_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise (ValueError if rc == _lib.VMR_EINVAL else EngineError)(msg)
+        self._keep = (xk, rk)
+        return self
+
     # -- helpers
     def _check(self, rc):
         if rc == 0:
@@ -144,6 +195,18 @@ class CaviEngine:
             return e.value
         self._check(self.lib.vmr_step(self._h, int(n_iters), None))
         return None
+
+    def fit_loop(self, max_iter, tol, decision):
+        """The realisation's convergence loop on the engine's side (reference model.py:405-426, 1021-1056).
+        Returns (trace rows [(iter, elbo, runtime, reached)], last ELBO, iterations, converged)."""
+        cap = max_iter // 10 + 2
+        n, its, conv, e = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        ri, rr = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        re, rt = np.empty(cap), np.empty(cap)
+        self._check(self.lib.vmr_fit_loop(self._h, int(max_iter), float(tol), int(decision), cap, C.byref(n), ri.ctypes.data,
+                                          re.ctypes.data, rt.ctypes.data, rr.ctypes.data, C.byref(e), C.byref(its), C.byref(conv)))
+        k = n.value
+        return list(zip(ri[:k].tolist(), re[:k].tolist(), rt[:k].tolist(), [bool(v) for v in rr[:k]])), e.value, its.value, bool(conv.value)
 
     def elbo(self):
         e = C.c_double()

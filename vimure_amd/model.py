@@ -19,7 +19,7 @@ from scipy.stats import poisson
 
 from ._log import setup_logging
 from .engine import CaviEngine, host_buffer
-from .tensor import is_sparse_like, to_dense_u8
+from .tensor import SparseTensor, is_sparse_like, to_dense_u8
 
 try:  # the reference is an sklearn estimator (model.py:28); keep that surface when sklearn is there
     from sklearn.base import BaseEstimator, TransformerMixin
@@ -78,8 +78,12 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 self.K = net.K
 
         dev_tensor = _is_torch(X)
-        if dev_tensor:
-            Xd = X
+        # a coordinate container (the reference's sptensor surface: subs / vals / shape) goes to the device as it is
+        # (vmr_create_coo) when the report lists can hold it; no dense [L,N,N,M] array is built then
+        coo = (not dev_tensor and is_sparse_like(X) and not self.undirected and extra.get("engine") is None
+               and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 63)))
+        if dev_tensor or coo or (extra.get("engine") is not None and is_sparse_like(X)):
+            Xd = X   # (with `engine` the data is on the device already: only the shape is needed)
             shape = tuple(int(s) for s in X.shape)
         else:
             Xd = to_dense_u8(X, "X")
@@ -99,7 +103,7 @@ class VimureModel(TransformerMixin, BaseEstimator):
             if extra.get("K") is not None:
                 self.K = int(extra["K"])
             else:
-                self.K = int(Xd.max()) + 1
+                self.K = (int(np.max(Xd.vals)) if is_sparse_like(Xd) else int(Xd.max())) + 1
                 warnings.warn(f"Parameter K was None. Defaulting to: {self.K}", UserWarning)
 
         if not hasattr(self, "R"):
@@ -116,9 +120,16 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 warnings.warn(msg, UserWarning)
                 self.R = None  # the engine treats NULL as all ones; no [L,N,N,M] float64 array is built
         Rd = self.R
-        if Rd is not None and not _is_torch(Rd):
+        if extra.get("engine") is not None:
+            Rd = None   # the engine already holds X and R on the device: no pass over the host copies
+        elif coo and (Rd is None or is_sparse_like(Rd)):
+            pass        # coordinate lists: handed to the engine as they are
+        elif coo:       # X as lists, R dense: the lists of its non-zeros
+            Rd = SparseTensor.fromarray(np.asarray(Rd) != 0)
+        elif Rd is not None and not _is_torch(Rd):
             Rd = to_dense_u8(Rd, "R")
-            Rd = (Rd != 0).astype(np.uint8)
+            if Rd.dtype != np.uint8 or Rd.max(initial=0) > 1:
+                Rd = (Rd != 0).astype(np.uint8)
 
         self.EPS = float(extra["EPS"]) if "EPS" in extra else DEFAULT_EPS
         self.bias0 = float(extra["bias0"]) if "bias0" in extra else DEFAULT_BIAS0
@@ -265,7 +276,10 @@ class VimureModel(TransformerMixin, BaseEstimator):
         eng = extra_params.get("engine")
         own_engine = eng is None
         keep = bool(extra_params.get("keep_engine", False)) and own_engine
-        if own_engine:
+        if own_engine and is_sparse_like(Xd):
+            eng = CaviEngine.from_coo(Xd.subs, Xd.vals, (self.L, self.N, self.N, self.M), R=None if Rd is None else Rd.subs,
+                                      K=self.K, mutuality=self.mutuality, eps=self.EPS, device=extra_params.get("device"))
+        elif own_engine:
             eng = CaviEngine(Xd, Rd, K=self.K, mutuality=self.mutuality, eps=self.EPS, device=extra_params.get("device"))
         elif (eng.L, eng.N, eng.M, eng.K, eng.mutuality) != (self.L, self.N, self.M, self.K, bool(self.mutuality)):
             raise ValueError("engine does not match the shape / K / mutuality of this fit")
@@ -311,25 +325,12 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 r, seed_r, st, final_seed = item
                 eng.set_state(st["gamma_shp"], st["gamma_rte"], st["phi_shp"], st["phi_rte"], st["nu_shp"], st["nu_rte"],
                               st["pr_rho"])   # (synchronises: the staging buffer is free again)
-                coincide, it, reached, elbo = 0, 1, False, -INF
                 t_loop = time.perf_counter()
-                while not reached and it <= self.max_iter:
-                    check = it == 1 or it % 10 == 0 or it == self.max_iter
-                    t0 = time.time()
-                    if check:
-                        old, elbo = elbo, eng.step(1, want_elbo=True)
-                        coincide = coincide + 1 if abs(elbo - old) < self.convergence_tol else 0
-                    else:
-                        eng.step(1)
-                    runtime = time.time() - t0
-                    if coincide > self.decision:
-                        reached = True
-                    if check and self.verbose:
-                        self.logger.debug(f"Realisation {r:2} | Iter {it:4} | ELBO value: {elbo:6.12f} | "
-                                          f"Reached convergence: {reached}")
-                    it += 1
-                    if (it - 1) % 10 == 0:
-                        trace.append((r, seed_r, it - 1, elbo, runtime, reached))
+                if not self.verbose:   # the whole loop on the engine's side (vmr_fit_loop): one call per realisation
+                    rows, elbo, _, _ = eng.fit_loop(self.max_iter, self.convergence_tol, self.decision)
+                    trace.extend((r, seed_r, it_, e_, rt_, rc_) for it_, e_, rt_, rc_ in rows)
+                else:
+                    elbo = self._loop_verbose(eng, r, seed_r, trace)
                 eng.sync()
                 self.loop_seconds += time.perf_counter() - t_loop
                 self._pull_params(eng)   # the small arrays of this realisation (rho stays on the device)
@@ -357,6 +358,27 @@ class VimureModel(TransformerMixin, BaseEstimator):
         self.trace = pd.DataFrame(trace, columns=cols)
         self.maxL = maxL
         return self
+
+    def _loop_verbose(self, eng, r, seed_r, trace):
+        """The reference's while-loop (model.py:405-426) step by step, with its DEBUG line per ELBO evaluation."""
+        coincide, it, reached, elbo = 0, 1, False, -INF
+        while not reached and it <= self.max_iter:
+            nxt = it if (it == 1 or it % 10 == 0 or it == self.max_iter) else min(self.max_iter, (it // 10 + 1) * 10)
+            if nxt > it:
+                eng.step(nxt - it)
+                it = nxt
+                eng.sync()
+            t0 = time.time()
+            old, elbo = elbo, eng.step(1, want_elbo=True)
+            runtime = time.time() - t0
+            coincide = coincide + 1 if abs(elbo - old) < self.convergence_tol else 0
+            if coincide > self.decision:
+                reached = True
+            self.logger.debug(f"Realisation {r:2} | Iter {it:4} | ELBO value: {elbo:6.12f} | Reached convergence: {reached}")
+            it += 1
+            if (it - 1) % 10 == 0:
+                trace.append((r, seed_r, it - 1, elbo, runtime, reached))
+        return elbo
 
     _SMALL = ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "nu_rte")
 

@@ -34,6 +34,15 @@ class SparseTensor:
         return cls(subs, A[subs], shape=A.shape, dtype=A.dtype)
 
 
+def layer_of(X, l):
+    """Layer l of a [L,N,N,M] tensor as a one-layer tensor of the same kind (COO container or dense array)."""
+    if is_sparse_like(X):
+        keep = np.asarray(X.subs[0]) == l
+        subs = (np.zeros(int(keep.sum()), np.int64),) + tuple(np.asarray(a)[keep] for a in X.subs[1:])
+        return SparseTensor(subs, np.asarray(X.vals)[keep], shape=(1,) + tuple(int(v) for v in X.shape[1:]))
+    return np.ascontiguousarray(np.asarray(X)[l:l + 1])
+
+
 def is_sparse_like(X):
     """Duck-typed COO tensor (ours, or a real sktensor.sptensor if the user has one)."""
     return hasattr(X, "subs") and hasattr(X, "vals") and hasattr(X, "shape")
