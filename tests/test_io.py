@@ -126,3 +126,26 @@ def test_igraph_like_input():
         net = read_from_igraph(G())
     X = net.X.toarray(int)
     assert net.N == 3 and X[0, 0, 1, 0] == 1 and X[0, 1, 2, 1] == 1 and X[0, 2, 0, 2] == 1 and X.sum() == 3
+
+
+def test_undirected_repeated_rows_sum_before_the_max_with_the_transpose():
+    """A repeated (layer, ego, alter, reporter) row of different weight survives drop_duplicates; the reference puts the rows
+    in a scipy COO matrix, whose duplicates ADD UP when `sparse_max(X, X.T)` converts it (utils.py:184-192, _io.py:276-285)."""
+    import pandas as pd
+    from scipy import sparse
+    from vimure_amd._io import read_from_edgelist
+    df = pd.DataFrame({"ego": ["a", "a", "b", "c"], "alter": ["b", "b", "a", "a"], "reporter": ["a", "a", "a", "c"],
+                       "weight": [1, 2, 1, 4], "layer": ["x"] * 4})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = read_from_edgelist(df, is_undirected=True, is_weighted=True)
+    X = net.X.toarray()
+    ids = dict(zip(net.nodeNames["name"], net.nodeNames["id"]))
+    a, b, c = ids["a"], ids["b"], ids["c"]
+    # what scipy does for reporter a: COO with the repeated entry, max with its transpose
+    A = sparse.coo_matrix(([1, 2, 1], ([a, a, b], [b, b, a])), shape=(3, 3))
+    gt = (A > A.T).astype(int)
+    ref = (gt.multiply(A - A.T) + A.T).toarray()
+    assert ref[a, b] == 3 and ref[b, a] == 3
+    assert np.array_equal(X[0, :, :, a], ref)
+    assert X[0, c, a, c] == 4 and X[0, a, c, c] == 4

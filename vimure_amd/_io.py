@@ -141,20 +141,21 @@ def read_from_edgelist(df, nodes: list = [], reporters: list = [], is_weighted: 
     keep = data > 0
     li, ei, ai, ri, data = li[keep], ei[keep], ai[keep], ri[keep], np.asarray(data)[keep]
     dense_key = ((li * N + ei) * N + ai) * N + ri
-    if is_undirected:   # element-wise max with the transpose, per (reporter, layer) (_io.py:283-285)
-        key_t = ((li * N + ai) * N + ei) * N + ri
+    # repeated (l, ego, alter, reporter) rows add up, as the scipy COO matrix the reference builds does (_io.py:276-281)
+    order = np.argsort(dense_key, kind="stable")
+    dense_key, data = dense_key[order], np.asarray(data)[order]
+    uniq, start = np.unique(dense_key, return_index=True)
+    data = np.add.reduceat(data, start) if len(start) else data
+    dense_key = uniq
+    if is_undirected:   # then the element-wise max with the transpose, per (reporter, layer) (_io.py:283-285, utils.sparse_max)
+        l_, e_, a_, r_ = np.unravel_index(dense_key, (L, N, N, N)) if len(dense_key) else (np.zeros(0, np.int64),) * 4
+        key_t = ((l_ * N + a_) * N + e_) * N + r_
         dense_key = np.concatenate([dense_key, key_t])
         data = np.concatenate([data, data])
         order = np.argsort(dense_key, kind="stable")
         dense_key, data = dense_key[order], data[order]
         uniq, start = np.unique(dense_key, return_index=True)
         data = np.maximum.reduceat(data, start) if len(start) else data
-        dense_key = uniq
-    else:               # repeated (l, ego, alter, reporter) rows add up, as a scipy COO matrix does
-        order = np.argsort(dense_key, kind="stable")
-        dense_key, data = dense_key[order], data[order]
-        uniq, start = np.unique(dense_key, return_index=True)
-        data = np.add.reduceat(data, start) if len(start) else data
         dense_key = uniq
     subs = np.unravel_index(dense_key, (L, N, N, N)) if len(dense_key) else tuple(np.zeros(0, np.int64) for _ in range(4))
     X = SparseTensor(tuple(np.asarray(s, dtype=np.int64) for s in subs), np.asarray(data), shape=(L, N, N, N))

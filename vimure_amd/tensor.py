@@ -56,7 +56,11 @@ def to_dense_u8(X, what="X"):
             raise ValueError(f"{what} entries must be integers in [0, 255] for the uint8 device layout")
         out = np.zeros(tuple(int(s) for s in X.shape), np.uint8)
         if len(vals):
-            out[tuple(np.asarray(s, dtype=np.int64) for s in X.subs)] = vals.astype(np.uint8)
+            subs = tuple(np.asarray(s, dtype=np.int64) for s in X.subs)
+            flat = np.ravel_multi_index(subs, out.shape)
+            if len(np.unique(flat)) != len(flat):
+                raise ValueError(f"{what} holds repeated (l, i, j, m) subscripts")
+            out[subs] = vals.astype(np.uint8)
         return out
     A = np.asarray(X)
     if A.dtype != np.uint8:
