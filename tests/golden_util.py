@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if not n.startswith("J_")]   # J_*: ingestion vectors, not model cases
+    return [n for n in names if not n.startswith(("J_", "K_"))]   # J_*: ingestion vectors, K_*: generator vectors -- not model cases
 
 
 def load_case(name):
