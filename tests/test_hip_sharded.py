@@ -49,3 +49,41 @@ def test_two_ranks_one_layer_each_equal_the_joint_fit():
         np.testing.assert_allclose(rho[0], d["fit_rho_f"][rank], rtol=1e-6, atol=1e-12)
         np.testing.assert_allclose(nu_shp, d["fit_nu_shp_f"], rtol=1e-7)
         assert next_seed == int(d["fit_final_seed"])
+
+
+def _worker_batch(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from tests.golden_util import load_case
+    from vimure_amd.batch import fit_datasets
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = load_case("D_self_mask")
+    data = {"a": (d["X"], d["R"]), "b": (d["X"][:1], d["R"][:1]), "c": (d["X"][1:], d["R"][1:])}
+    df = fit_datasets(data, K=2, seeds=[1, 2], dist=dist, device=0, workers=2, num_realisations=2, max_iter=21)
+    q.put((rank, df[["dataset", "layer", "seed", "iters"]].values.tolist(), df["elbo"].tolist()))
+    dist.destroy_process_group()
+
+
+def test_fit_datasets_sharded_over_two_ranks_equals_one_process():
+    """The (dataset, layer) units of the batch driver sharded over two ranks (one process per GPU in production; both on
+    this box's GPU here), rows gathered with one all_gather: every rank ends with the table one process computes."""
+    import torch.multiprocessing as mp
+    from tests.golden_util import load_case
+    from vimure_amd.batch import fit_datasets
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_batch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = load_case("D_self_mask")
+    data = {"a": (d["X"], d["R"]), "b": (d["X"][:1], d["R"][:1]), "c": (d["X"][1:], d["R"][1:])}
+    one = fit_datasets(data, K=2, seeds=[1, 2], workers=1, num_realisations=2, max_iter=21)
+    for rank, keys, elbos in got:
+        assert keys == one[["dataset", "layer", "seed", "iters"]].values.tolist()
+        np.testing.assert_allclose(elbos, one["elbo"].values, rtol=1e-9)

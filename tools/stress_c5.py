@@ -51,10 +51,16 @@ def main():
                            "TBps": v["bytes_per_launch"] / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e12 if v["ms"] > 0 and v["bytes_per_launch"] else None}
                        for k, v in prof.items() if v["launches"]}}
     if a.parity:
-        from oracle import cavi_ref
-        X = net.X.cpu().numpy()
-        c = cavi_ref.CRef(X, None, a.K, True, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), host.gamma_shp, host.gamma_rte,
-                          host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+        # the coordinate-list oracle: no dense 64 GB tensor on the host
+        from oracle import cavi_coo
+        from tests.test_hip_configs import _coo_from_device
+        subs, vals = _coo_from_device(net.X)
+        del net
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        c = cavi_coo.CooRef((subs, vals), None, (1, a.N, a.N, a.M), a.K, True, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0), host.gamma_shp,
+                            host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+        print(f"oracle prepared in {time.perf_counter() - t0:.1f} s", flush=True)
         t0 = time.perf_counter()
         c.cavi_step()
         tc = time.perf_counter() - t0

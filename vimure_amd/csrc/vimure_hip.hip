@@ -1738,6 +1738,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
     }
+    bool quick_w2 = false;   // walk 1 found the prefetched trips to be full rounds of LDS levels (see there)
     double dfc = 0.0;   // 1 - sum_k rho_k of this lane's tie, 0 when that is rounding
     bool irr = false;   // (wave-uniform) some tie of the step has a non-zero dfc
     double er[K];       // exp(rho) of this lane's tie (ELBO, model.py:971)
@@ -1824,10 +1825,36 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         }
       };
       const int trips1 = (g.dbg & 16) ? 0 : trips;   // (timing experiment: no walk 1)
-      auto walk1 = [&](auto near) {
+      // The common step: its first SP_PF trips (the prefetched ones) are all full rounds and none of their reports is in a
+      // level beyond the LDS tables.  Then the SP_PF table reads are issued back to back and consumed afterwards -- one LDS
+      // latency instead of SP_PF, and no branch per trip (an empty slot has x = 0 and reads row 0).
+      bool quick = R >= SP_PF && trips1 > 0;
+      if (quick) {
+        bool far = false;
 #pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          if (j < trips1) trip1(pe[j], j, near);   // wave-uniform
+        for (int j = 0; j < SP_PF; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
+        quick = !__any(far);
+      }
+      quick_w2 = quick;
+      auto walk1 = [&](auto near) {
+        if (quick) {
+          double f[SP_PF][K];
+#pragma unroll
+          for (int j = 0; j < SP_PF; ++j) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) f[j][k] = F[ENT_YM(pe[j]) * K + k];
+          }
+#pragma unroll
+          for (int j = 0; j < SP_PF; ++j) {
+            const double dx = (double)ENT_X(pe[j]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) U[k] = fma(dx, f[j][k], U[k]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < SP_PF; ++j) {
+            if (j < trips1) trip1(pe[j], j, near);   // wave-uniform
+          }
         }
         if (trips1 > SP_PF) {   // long steps: rolling prefetch one trip ahead
           unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
@@ -1904,10 +1931,23 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           }
         }
       };
+      const bool quick2 = UPDATE && !ELBO && a.do_hist && R >= SP_PF && !irr && !(g.dbg & 16) && quick_w2;
       auto walk2 = [&](auto near) {
+        if (quick2) {   // (as in walk 1: the prefetched trips are full rounds of LDS levels; this lane's own rho)
 #pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          if (j < trips) trip2(pe[j], j, near);
+          for (int j = 0; j < SP_PF; ++j) {
+            const unsigned ym = ENT_YM(pe[j]), x = ENT_X(pe[j]);
+            const double dx = (double)x;
+            if (x != 0u) {
+#pragma unroll
+              for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < SP_PF; ++j) {
+            if (j < trips) trip2(pe[j], j, near);
+          }
         }
         if (trips > SP_PF) {
           unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
