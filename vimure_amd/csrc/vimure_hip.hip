@@ -1185,10 +1185,16 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 // sum_m R[t,m] X[mirror(t),m] (the ELBO's mirror sum, a constant of the data).  A sweep reads 4 B per report (plus
 // the padding) + rho/log-prior instead of 1 B per (tie, reporter).  The dense tensor is freed once the lists exist.
 // ==========================================================================================
+// SP_PF: slots per lane that are prefetched one step ahead (the first SP_PF*64 of a step).  Depth beats occupancy here: 8 trips
+// cover almost every step of the benchmark data (4.1 reports per tie), so the walks never wait for a load of their own;
+// measured at L=4 N=2000 M=200: 3 trips at 6 waves/SIMD 0.281 ms, 5 at 5: 0.257, 6 at 5: 0.251, 8 at 4: 0.239-0.248.
 #ifndef SP_PF
-#define SP_PF 3
+#define SP_PF 8
 #endif
-// SP_PF: slots per lane that are prefetched one step ahead (the first SP_PF*64 of a step)
+#ifndef SP_QB
+#define SP_QB 3   // of those, the trips the common step takes in one batch (k_rho_sp's "quick" path); <= SP_PF.  (Batching all
+                  // full rounds among the prefetched trips, 4 or 5 at a time, was measured slower: fewer steps qualify.)
+#endif
 #define ENT_YM(e) ((e) & 0x7ffffu)
 #define ENT_INR(e) (((e) >> 19) & 1u)
 #define ENT_OW(e) ((int)(((e) >> 20) & 63u))
@@ -1574,7 +1580,7 @@ __device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v
 #define SP_TPB_MAX 1024
 #endif
 #ifndef SP_WPE
-#define SP_WPE 6   // waves per SIMD the kernel is compiled for (80 VGPRs; forcing 8, i.e. 64 VGPRs, spills: measured slower)
+#define SP_WPE 4   // waves per SIMD the kernel is compiled for (128 VGPRs: room for SP_PF = 8 prefetched trips, see there)
 #endif
 template <int K, bool MUT, bool UPDATE, bool ELBO>
 __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
@@ -1637,8 +1643,11 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   unsigned clsn = 0, qn = 0;
   double lpn[K], rn[K];
   unsigned pen[SP_PF];
-  unsigned ea1 = 0, et1 = 0, ee1 = 0, ea2 = 0, et2 = 0, ee2 = 0;
+  unsigned ea1 = 0, et1 = 0, ee1 = 0;
+  unsigned rg2 = 0;   // lanes 0..2: the slot range of the step after next.  Kept in a VECTOR register until it is needed, one step
+                      // later: read as scalars (uniform address), the three values were waited for on the spot, in every step.
   auto fetch_range = [&](long long s, unsigned& ea, unsigned& et, unsigned& ee) { ea = rsl[2 * s]; et = rsl[2 * s + 1]; ee = rsl[2 * s + 2]; };
+  auto fetch_range_v = [&](long long s) { rg2 = lane < 3 ? rsl[2 * s + lane] : 0u; };
   auto fetch_tie = [&](long long s, unsigned ea, unsigned ee) {
     const size_t t = (size_t)s * 64 + lane;
     const bool ok = t < T;
@@ -1659,7 +1668,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   const long long sfirst = s0 + wv;
   if (sfirst < s1_) {
     fetch_range(sfirst, ea1, et1, ee1);
-    if (sfirst + nw < s1_) fetch_range(sfirst + nw, ea2, et2, ee2);
+    if (sfirst + nw < s1_) fetch_range_v(sfirst + nw);
     fetch_tie(sfirst, ea1, ee1);
   }
   __syncthreads();   // tables
@@ -1773,9 +1782,11 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
       }
     }
     // next steps' loads
-    ea1 = ea2; et1 = et2; ee1 = ee2;
     if (s + nw < s1_) {
-      if (s + 2 * nw < s1_) fetch_range(s + 2 * nw, ea2, et2, ee2);
+      ea1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 0);
+      et1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 1);
+      ee1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 2);
+      if (s + 2 * nw < s1_) fetch_range_v(s + 2 * nw);
       fetch_tie(s + nw, ea1, ee1);
     }
     double Tt = 0.0;
@@ -1825,36 +1836,35 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         }
       };
       const int trips1 = (g.dbg & 16) ? 0 : trips;   // (timing experiment: no walk 1)
-      // The common step: its first SP_PF trips (the prefetched ones) are all full rounds and none of their reports is in a
-      // level beyond the LDS tables.  Then the SP_PF table reads are issued back to back and consumed afterwards -- one LDS
-      // latency instead of SP_PF, and no branch per trip (an empty slot has x = 0 and reads row 0).
-      bool quick = R >= SP_PF && trips1 > 0;
+      // The common step: its first SP_QB trips are all full rounds and none of their reports is in a level beyond the LDS
+      // tables.  Then the SP_QB table reads are issued back to back and consumed afterwards -- one LDS latency instead of
+      // SP_QB, and no branch per trip (an empty slot has x = 0 and reads row 0).
+      bool quick = R >= SP_QB && trips1 > 0;
       if (quick) {
         bool far = false;
 #pragma unroll
-        for (int j = 0; j < SP_PF; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
+        for (int j = 0; j < SP_QB; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
         quick = !__any(far);
       }
       quick_w2 = quick;
       auto walk1 = [&](auto near) {
         if (quick) {
-          double f[SP_PF][K];
+          double f[SP_QB][K];
 #pragma unroll
-          for (int j = 0; j < SP_PF; ++j) {
+          for (int j = 0; j < SP_QB; ++j) {
 #pragma unroll
             for (int k = 0; k < K; ++k) f[j][k] = F[ENT_YM(pe[j]) * K + k];
           }
 #pragma unroll
-          for (int j = 0; j < SP_PF; ++j) {
+          for (int j = 0; j < SP_QB; ++j) {
             const double dx = (double)ENT_X(pe[j]);
 #pragma unroll
             for (int k = 0; k < K; ++k) U[k] = fma(dx, f[j][k], U[k]);
           }
-        } else {
+        }
 #pragma unroll
-          for (int j = 0; j < SP_PF; ++j) {
-            if (j < trips1) trip1(pe[j], j, near);   // wave-uniform
-          }
+        for (int j = 0; j < SP_PF; ++j) {
+          if ((j >= SP_QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
         }
         if (trips1 > SP_PF) {   // long steps: rolling prefetch one trip ahead
           unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
@@ -1931,23 +1941,40 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           }
         }
       };
-      const bool quick2 = UPDATE && !ELBO && a.do_hist && R >= SP_PF && !irr && !(g.dbg & 16) && quick_w2;
+      const bool quick2 = UPDATE && a.do_hist && R >= SP_QB && !irr && !(g.dbg & 16) && quick_w2;
       auto walk2 = [&](auto near) {
-        if (quick2) {   // (as in walk 1: the prefetched trips are full rounds of LDS levels; this lane's own rho)
+        if (quick2) {   // (as in walk 1: the first SP_QB trips are full rounds of LDS levels; this lane's own rho)
+          double in_[SP_QB];
 #pragma unroll
-          for (int j = 0; j < SP_PF; ++j) {
+          for (int j = 0; j < SP_QB; ++j) {
             const unsigned ym = ENT_YM(pe[j]), x = ENT_X(pe[j]);
             const double dx = (double)x;
             if (x != 0u) {
 #pragma unroll
               for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
             }
-          }
-        } else {
+            if (ELBO) {   // the SP_QB logarithms are independent: straight-line, so that they interleave
+              unsigned y = (unsigned)((float)ym * rcp_mp);
+              if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+              const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
+              double inner = 0.0;
 #pragma unroll
-          for (int j = 0; j < SP_PF; ++j) {
-            if (j < trips) trip2(pe[j], j, near);
+              for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+              in_[j] = (ENT_INR(pe[j]) ? inner : 0.0) + eps;
+            }
           }
+          if (ELBO) {
+#pragma unroll
+            for (int j = 0; j < SP_QB; ++j) {
+              const unsigned x = ENT_X(pe[j]);
+              const double lg = log_pos(in_[j]);
+              e_log += x != 0u ? (double)x * lg : 0.0;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < SP_PF; ++j) {
+          if ((j >= SP_QB || !quick2) && j < trips) trip2(pe[j], j, near);
         }
         if (trips > SP_PF) {
           unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
@@ -2915,7 +2942,7 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
     // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
     auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 8)));
+    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 12)));
     auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {   // resident waves per CU: LDS and register limits
       const size_t b = shmem_sp(g, tpb, yt, hc, upd, false, hist);
       if (b > SP_LDS_MAX) return 0;
