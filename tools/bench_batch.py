@@ -29,7 +29,8 @@ def main():
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     procs = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     if procs:   # warm the worker processes up (interpreter start, imports, first kernel load): a pool serves many calls
-        fit_datasets({"w": data["vil0"]}, K=2, seeds=range(procs * 4), num_realisations=1, max_iter=11, workers=workers, processes=procs)
+        fit_datasets({f"w{i}": data["vil0"] for i in range(2 * procs * workers)}, K=2, seeds=range(2), num_realisations=1, max_iter=11,
+                     workers=workers, processes=procs)
         t0 = time.perf_counter()
     df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=workers, processes=procs)
     dt = time.perf_counter() - t0

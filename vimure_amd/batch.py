@@ -6,7 +6,8 @@ A small fit is bound by the latency of its dependent kernel launches (3 per swee
 GPU: one fit keeps a few per cent of an MI355X busy.  Units therefore run CONCURRENTLY: `workers` host threads, each
 driving its own `CaviEngine` (one handle = one HIP stream; handles are independent), so the kernels of several fits
 overlap on the device -- and, because the threads of one process still meet in the HIP runtime's launch path (8 threads:
-1.5x one thread), `processes` worker processes beside each other on the same GPU (4 processes x 2 threads: 3.6x).
+1.5x one thread), `processes` worker processes beside each other on the same GPU (4 processes x 2 threads: 3.6x), all threads
+pulling units from one shared queue.
 One engine per (dataset, layer) holds the data; all seeds of that unit reuse it.
 Across GPUs the units are sharded by `vimure_amd.multifit` (one process per GPU, ELBO gather at the end).
 `karnataka_tables` / `run_karnataka` produce the four result tables of the reference driver (karnataka.py:200-318).
@@ -78,29 +79,100 @@ def _run_units(jobs, workers):
         return [f.result() for f in [ex.submit(j) for j in jobs]]
 
 
-# ---- worker processes (several per GPU): top-level functions, so that the spawn start method can pickle them
-def _proc_init():
+# ---- worker processes (several per GPU) ------------------------------------------------------------------------
+# A persistent group of spawned processes (a forked child must not inherit an initialised GPU runtime), each running
+# `workers` threads that pull units from ONE shared queue -- so the schedule balances at the grain of a thread -- and
+# push (tag, rows) back.  Units travel compactly: coordinate lists as uint16 / int32 columns and uint8 counts (a
+# self-reporter mask of N = 600 is 720 k entries: 23 MB as int64 columns, 6 MB on the wire).
+class _Coo:
+    """What a worker rebuilds from the wire: duck-typed coordinate container (subs, vals, shape)."""
+
+    def __init__(self, subs, vals, shape):
+        self.subs, self.vals, self.shape = tuple(subs), vals, tuple(shape)
+
+
+def _wire(A):
+    if A is None or not is_sparse_like(A):
+        return A
+    shape = tuple(int(v) for v in A.shape)
+    subs = tuple(np.ascontiguousarray(a, dtype=np.uint16 if shape[d] <= 65536 else np.int32) for d, a in enumerate(A.subs))
+    vals = np.asarray(A.vals)
+    if len(vals) == 0 or (vals.min() >= 0 and vals.max() <= 255):
+        vals = vals.astype(np.uint8)
+    return ("coo", subs, vals, shape)
+
+
+def _unwire(W):
+    if isinstance(W, tuple) and len(W) == 4 and isinstance(W[0], str) and W[0] == "coo":
+        return _Coo(W[1], W[2], W[3])
+    return W
+
+
+def _worker_main(tasks, results, workers):
     warnings.simplefilter("ignore")
 
+    def loop():
+        while True:
+            t = tasks.get()
+            if t is None:
+                tasks.put(None)   # let the other threads (and processes) see it too
+                return
+            call, tag, Xw, Rw, K, seeds, mutuality, device, fit_kwargs = t
+            try:
+                rows, _ = _fit_unit(_unwire(Xw), _unwire(Rw), K, seeds, mutuality, device, tag, None, fit_kwargs)
+                results.put((call, tag, rows, None))
+            except BaseException as e:   # the caller re-raises
+                results.put((call, tag, None, f"{type(e).__name__}: {e}"))
+    th = [threading.Thread(target=loop, name=f"vmr-fit-{i}") for i in range(max(1, workers))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
 
-def _proc_units(payload):
-    """One chunk of units in a worker process: [(tag, Xl, Rl)] -> [(tag, rows)] (threads inside the process as usual)."""
-    chunk, K, seeds, mutuality, device, workers, fit_kwargs = payload
-    res = _run_units([lambda u=u: (u[0], _fit_unit(u[1], u[2], K, seeds, mutuality, device, u[0], None, fit_kwargs)[0]) for u in chunk],
-                     workers)
-    return res
+
+class _WorkerGroup:
+    def __init__(self, processes, workers):
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        self.tasks, self.results, self.calls = ctx.Queue(), ctx.Queue(), 0
+        self.procs = [ctx.Process(target=_worker_main, args=(self.tasks, self.results, workers), daemon=True) for _ in range(processes)]
+        for p in self.procs:
+            p.start()
+
+    def run(self, units, K, seeds, mutuality, device, fit_kwargs):
+        self.calls += 1
+        for tag, Xl, Rl in units:
+            self.tasks.put((self.calls, tag, _wire(Xl), _wire(Rl), K, seeds, mutuality, device, fit_kwargs))
+        out = {}
+        while len(out) < len(units):
+            try:
+                call, tag, rows, err = self.results.get(timeout=5.0)
+            except Exception:   # queue.Empty: make sure somebody is still working
+                if not all(p.is_alive() for p in self.procs):
+                    raise RuntimeError("a vimure_amd worker process died")
+                continue
+            if call != self.calls:
+                continue   # (left over from a call that raised)
+            if err is not None:
+                raise RuntimeError(f"unit {tag}: {err}")
+            out[tag] = rows
+        return out
+
+    def shutdown(self):
+        self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
 
 
 _pools = {}
 
 
-def _pool(processes):
-    """A persistent pool of worker processes (spawned: a forked child must not inherit an initialised GPU runtime)."""
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
-    if processes not in _pools:
-        _pools[processes] = ProcessPoolExecutor(max_workers=processes, mp_context=mp.get_context("spawn"), initializer=_proc_init)
-    return _pools[processes]
+def _pool(processes, workers):
+    if (processes, workers) not in _pools:
+        _pools[(processes, workers)] = _WorkerGroup(processes, workers)
+    return _pools[(processes, workers)]
 
 
 def shutdown_pools():
@@ -110,16 +182,8 @@ def shutdown_pools():
 
 
 def _run_units_processes(units, K, seeds, mutuality, device, processes, workers, fit_kwargs):
-    """units: [(tag, Xl, Rl)] sorted longest first; dealt round-robin into 4 chunks per process (load balance), chunks run in the
-    pool.  Returns {tag: rows}."""
-    nchunk = max(1, min(len(units), 4 * processes))
-    chunks = [units[i::nchunk] for i in range(nchunk)]
-    futs = [_pool(processes).submit(_proc_units, (c, K, seeds, mutuality, device, workers, fit_kwargs)) for c in chunks]
-    out = {}
-    for f in futs:
-        for tag, rows in f.result():
-            out[tag] = rows
-    return out
+    """units: [(tag, Xl, Rl)] sorted longest first, each a task of the worker group.  Returns {tag: rows}."""
+    return _pool(processes, max(1, workers)).run(units, K, list(seeds), mutuality, device, fit_kwargs)
 
 
 def fit_layers(X, R=None, K=2, seeds: Iterable[int] = range(10), layer_names: Sequence[str] = None, mutuality=True,
