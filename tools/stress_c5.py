@@ -44,6 +44,7 @@ def main():
     eng.step(a.steps)
     eng.sync()
     dt = time.perf_counter() - t0
+    eng.step(1, want_elbo=True)   # (outside the timed sweeps: the ELBO variant of the rho pass, for the per-kernel table)
     prof = eng.profile_read()
     out = {"shape": [1, a.N, a.N, a.M], "K": a.K, "nnz": nnz, "sweeps_per_s": a.steps / dt, "ms_per_sweep": 1e3 * dt / a.steps,
            "elbo_after_1": e1,

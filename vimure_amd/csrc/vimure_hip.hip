@@ -1191,6 +1191,9 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 #ifndef SP_PF
 #define SP_PF 8
 #endif
+#ifndef SP_PF_ELBO2
+#define SP_PF_ELBO2 6
+#endif
 #ifndef SP_QB
 #define SP_QB 3   // of those, the trips the common step takes in one batch (k_rho_sp's "quick" path); <= SP_PF.  (Batching all
                   // full rounds among the prefetched trips, 4 or 5 at a time, was measured slower: fewer steps qualify.)
@@ -1582,9 +1585,15 @@ __device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v
 #ifndef SP_WPE
 #define SP_WPE 4   // waves per SIMD the kernel is compiled for (128 VGPRs: room for SP_PF = 8 prefetched trips, see there)
 #endif
+// Prefetch depth of a variant: as deep as its registers allow without spilling (128 VGPRs at 4 waves/SIMD; the ELBO
+// variants and many categories carry more state per tie)
+__host__ __device__ constexpr int sp_pf(int K, bool elbo) {
+  return elbo ? (K <= 2 ? SP_PF_ELBO2 : (K <= 4 ? 4 : 3)) : (K <= 5 ? SP_PF : 4);
+}
 template <int K, bool MUT, bool UPDATE, bool ELBO>
 __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int PF = sp_pf(K, ELBO), QB = SP_QB < PF ? SP_QB : PF;   // prefetched trips per step; trips of the batched path
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int Mp = g.Mp;
@@ -1638,11 +1647,11 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
   const double* Eth = a.par + o.E_th + (size_t)l * Mp;
 
-  // Software pipeline per wave: while step s is processed, the per-tie values and the first SP_PF*64 slots of
+  // Software pipeline per wave: while step s is processed, the per-tie values and the first PF*64 slots of
   // the wave's next step and the slot range of the one after are in flight.
   unsigned clsn = 0, qn = 0;
   double lpn[K], rn[K];
-  unsigned pen[SP_PF];
+  unsigned pen[PF];
   unsigned ea1 = 0, et1 = 0, ee1 = 0;
   unsigned rg2 = 0;   // lanes 0..2: the slot range of the step after next.  Kept in a VECTOR register until it is needed, one step
                       // later: read as scalars (uniform address), the three values were waited for on the spot, in every step.
@@ -1658,7 +1667,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
     if ((UPDATE || ELBO) && ok) load_k<K>(lpl + t * K, lpn);
     if (!UPDATE && ok && a.do_hist != 2) load_k<K>(rl + t * K, rn);
 #pragma unroll
-    for (int j = 0; j < SP_PF; ++j) {
+    for (int j = 0; j < PF; ++j) {
       const unsigned q = (unsigned)lane + (unsigned)j * 64;
       unsigned v = 0u;
       if (q < ee - ea) v = El[(size_t)ea + q];
@@ -1738,11 +1747,11 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
     const int trips = (int)((nt + 63) >> 6);
     const bool has_rest = ee1 > et1;
     double lp[K], r[K];
-    unsigned pe[SP_PF];
+    unsigned pe[PF];
 #pragma unroll
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
 #pragma unroll
-    for (int j = 0; j < SP_PF; ++j) pe[j] = pen[j];
+    for (int j = 0; j < PF; ++j) pe[j] = pen[j];
     if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
@@ -1836,40 +1845,40 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         }
       };
       const int trips1 = (g.dbg & 16) ? 0 : trips;   // (timing experiment: no walk 1)
-      // The common step: its first SP_QB trips are all full rounds and none of their reports is in a level beyond the LDS
-      // tables.  Then the SP_QB table reads are issued back to back and consumed afterwards -- one LDS latency instead of
-      // SP_QB, and no branch per trip (an empty slot has x = 0 and reads row 0).
-      bool quick = R >= SP_QB && trips1 > 0;
+      // The common step: its first QB trips are all full rounds and none of their reports is in a level beyond the LDS
+      // tables.  Then the QB table reads are issued back to back and consumed afterwards -- one LDS latency instead of
+      // QB, and no branch per trip (an empty slot has x = 0 and reads row 0).
+      bool quick = R >= QB && trips1 > 0;
       if (quick) {
         bool far = false;
 #pragma unroll
-        for (int j = 0; j < SP_QB; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
+        for (int j = 0; j < QB; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
         quick = !__any(far);
       }
       quick_w2 = quick;
       auto walk1 = [&](auto near) {
         if (quick) {
-          double f[SP_QB][K];
+          double f[QB][K];
 #pragma unroll
-          for (int j = 0; j < SP_QB; ++j) {
+          for (int j = 0; j < QB; ++j) {
 #pragma unroll
             for (int k = 0; k < K; ++k) f[j][k] = F[ENT_YM(pe[j]) * K + k];
           }
 #pragma unroll
-          for (int j = 0; j < SP_QB; ++j) {
+          for (int j = 0; j < QB; ++j) {
             const double dx = (double)ENT_X(pe[j]);
 #pragma unroll
             for (int k = 0; k < K; ++k) U[k] = fma(dx, f[j][k], U[k]);
           }
         }
 #pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          if ((j >= SP_QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
+        for (int j = 0; j < PF; ++j) {
+          if ((j >= QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
         }
-        if (trips1 > SP_PF) {   // long steps: rolling prefetch one trip ahead
-          unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
+        if (trips1 > PF) {   // long steps: rolling prefetch one trip ahead
+          unsigned q = (unsigned)lane + (unsigned)PF * 64;
           unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = SP_PF; j < trips; ++j) {
+          for (int j = PF; j < trips; ++j) {
             const unsigned cur = nx;
             q += 64;
             nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
@@ -1941,19 +1950,19 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           }
         }
       };
-      const bool quick2 = UPDATE && a.do_hist && R >= SP_QB && !irr && !(g.dbg & 16) && quick_w2;
+      const bool quick2 = UPDATE && a.do_hist && R >= QB && !irr && !(g.dbg & 16) && quick_w2;
       auto walk2 = [&](auto near) {
-        if (quick2) {   // (as in walk 1: the first SP_QB trips are full rounds of LDS levels; this lane's own rho)
-          double in_[SP_QB];
+        if (quick2) {   // (as in walk 1: the first QB trips are full rounds of LDS levels; this lane's own rho)
+          double in_[QB];
 #pragma unroll
-          for (int j = 0; j < SP_QB; ++j) {
+          for (int j = 0; j < QB; ++j) {
             const unsigned ym = ENT_YM(pe[j]), x = ENT_X(pe[j]);
             const double dx = (double)x;
             if (x != 0u) {
 #pragma unroll
               for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
             }
-            if (ELBO) {   // the SP_QB logarithms are independent: straight-line, so that they interleave
+            if (ELBO) {   // the QB logarithms are independent: straight-line, so that they interleave
               unsigned y = (unsigned)((float)ym * rcp_mp);
               if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
               const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
@@ -1965,7 +1974,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           }
           if (ELBO) {
 #pragma unroll
-            for (int j = 0; j < SP_QB; ++j) {
+            for (int j = 0; j < QB; ++j) {
               const unsigned x = ENT_X(pe[j]);
               const double lg = log_pos(in_[j]);
               e_log += x != 0u ? (double)x * lg : 0.0;
@@ -1973,13 +1982,13 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           }
         }
 #pragma unroll
-        for (int j = 0; j < SP_PF; ++j) {
-          if ((j >= SP_QB || !quick2) && j < trips) trip2(pe[j], j, near);
+        for (int j = 0; j < PF; ++j) {
+          if ((j >= QB || !quick2) && j < trips) trip2(pe[j], j, near);
         }
-        if (trips > SP_PF) {
-          unsigned q = (unsigned)lane + (unsigned)SP_PF * 64;
+        if (trips > PF) {
+          unsigned q = (unsigned)lane + (unsigned)PF * 64;
           unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = SP_PF; j < trips; ++j) {
+          for (int j = PF; j < trips; ++j) {
             const unsigned cur = nx;
             q += 64;
             nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
