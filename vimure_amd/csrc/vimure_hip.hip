@@ -64,6 +64,7 @@ struct Geo {
   int hc;       // how many of them are accumulated in LDS (dense tiles: 0..HC_MAX); the rest goes to global atomics
   int yt;       // report lists: levels of the factor table F the rho pass keeps in LDS; the rest is read from global
   int fuse_full; // rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
+  int ml;        // report lists with mask lists: the rho / statistics pass sums rho over the listed reporters too (A[Mp][K] in LDS)
   int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
                 // k_hist after the rho pass (two passes over X per sweep instead of one)
   int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
@@ -124,6 +125,8 @@ struct vmr_ctx {
   bool h_valid = false;        // H matches the current rho
   double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
   bool f_valid = false;        // slotF matches the current rho
+  bool a_valid = false;        // slotA holds the mask-list sums of the current rho (summed by the last rho / statistics pass)
+  bool a_zero = true;          // slotA is known to be all zero
   bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
   bool h_zero = false;         // k_fin_gamma consumed H and slotF: both are all zero, ready for the rho pass
   bool fin_attr = false, ml_attr = false;
@@ -1477,6 +1480,8 @@ struct SpArgs {
   int Gl, all_full;
   int do_hist;        // 1: accumulate the statistics H; 2: "count mode" (vmr_create): rho = (0, 1, 0, ..) for every tie, slot 1 gets sum x
   int yt, hc;         // levels (mirror counts 0..) of F / of the statistics H held in LDS
+  double* slotA;      // sum_a: the pass also sums the (new) rho over the listed reporters of the partial mask rows, A[l][m][k]
+  int sum_a;          // (what k_mask_lists does in a pass of its own), into this workgroup's slot of slotA
 };
 
 // Per-report factor of the rho update, a function of (reporter m, mirror count y, category k) only:
@@ -1604,6 +1609,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   const int nHc = (int)hcm * (K - 1);
   double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                 // [K-1][hc][Mp]: categories 1..K-1
   double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)Mp * 8 : 0;
+  double* As = reinterpret_cast<double*>(smem + off); off += a.sum_a ? (size_t)Mp * K * 8 : 0;   // [Mp][K], see SpArgs::sum_a
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
   // wave-private, [K][64], for the rest of a step: the ties' sums U, then their new rho (ELBO variants: exp(rho) there and
@@ -1619,6 +1625,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   const double* Fl = a.Fg + (size_t)l * g.Y * Mp * K;
   for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
+  if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
   if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
   const double* lut = a.lutg + (size_t)l * g.W * 256;
   for (int w = tid; w < g.W; w += nthr) {
@@ -1738,6 +1745,31 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
     e_log += dx * log_pos(inner + eps);
   };
 
+  // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749).  Lanes of a
+  // wave are consecutive ties (i, j..j+63): with a self-reporter mask one of the two listed reporters is the same for (almost)
+  // all of them -- reduced across the wave before ONE add -- and the other one differs from lane to lane.
+  auto add_lists = [&](size_t t, bool on, const double (&rr)[K]) {
+    unsigned q0 = 0, q1 = 0;
+    if (on) { q0 = rql[t]; q1 = rql[t + 1]; }
+    for (unsigned i = 0;; ++i) {
+      const bool v = q0 + i < q1;
+      const unsigned long long vm = __ballot(v);
+      if (vm == 0ull) break;
+      const int m = v ? (int)Rml[q0 + i] : -1;
+      const int m0 = __builtin_amdgcn_readlane(m, __builtin_ctzll(vm));
+      if (__all(!v || m == m0)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double sm_ = wave_sum(v ? rr[k] : 0.0);
+          if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
+        }
+      } else if (v) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
+      }
+    }
+  };
+
   for (long long s = sfirst; s < s1_; s += nw) {
     const size_t t = (size_t)s * 64 + lane;
     const bool act = t < T;
@@ -1789,6 +1821,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
         for (int k = 0; k < K; ++k) accF[k] += r[k];
       }
+      if (!ELBO && a.sum_a) add_lists(t, act && cls == 2u, r);
     }
     // next steps' loads
     if (s + nw < s1_) {
@@ -1923,6 +1956,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
         for (int k = 0; k < K; ++k) accF[k] += rowfull ? r[k] : 0.0;
       }
+      if (a.sum_a) add_lists(t, act && cls == 2u, r);
       if (has_rest) wave_sync();   // (U of the rest is consumed; without the ELBO rt aliases ut)
       put_rho(done);
       if (has_rest) wave_sync();
@@ -2020,6 +2054,13 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
       }
     }
   }
+  if (a.sum_a) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K], as k_mask_lists)
+    double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
+    for (int q = tid; q < g.M * K; q += nthr) {
+      const double v = As[q];
+      if (v != 0.0) atomicAdd(&out[q], v);
+    }
+  }
   if (UPDATE || (!ELBO && a.do_hist == 1)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -2114,6 +2155,9 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
 // Threads take (y, m) items of H (coalesced, all copies in flight at once), then one thread per reporter
 // finishes gamma.  consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for
 // the rho pass that follows.
+// (Finishing the previous sweep here too -- k_fin_rho's fold of the H copies and the nu update, for handles of one layer, so
+// that a small fit's sweep is two dependent launches instead of three -- was built and measured: one workgroup folding the 8
+// copies takes 38-83 us against 2 x 16-25 us for the two kernels.  Not kept.)
 __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, double* slotA, double* slotF,
                                                        double* lutg, double* Fg, int do_phi, int consume, Geo g) {
   extern __shared__ double dyn[];   // s1[Mp]: sum_{y,k} w1 H per reporter; gthn[Mp]: the new G_theta
@@ -2432,6 +2476,7 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
 static size_t shmem_sp(const Geo& g, int tpb, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
   return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)g.W * 8 + 128 +
+         (g.ml ? lb : 0) +
          (size_t)(tpb / 64) * 64 * g.K * 8 * (elbo ? 2 : 1) + 16;
 }
 #define SP_LDS_MAX (160 * 1024)
@@ -2531,9 +2576,16 @@ static int ensure_h_folded(vmr_ctx* h) {
   return VMR_OK;
 }
 
-static SpArgs sp_args(const vmr_ctx* h, const SpShape& sh, int do_hist) {
+static SpArgs sp_args(const vmr_ctx* h, const SpShape& sh, int do_hist, int sum_a = 0) {
   return SpArgs{h->E, h->rs, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-                h->rq, h->Rm, h->rbase, h->Fg, 1, h->all_full, do_hist, sh.yt, sh.hc};
+                h->rq, h->Rm, h->rbase, h->Fg, 1, h->all_full, do_hist, sh.yt, sh.hc, h->slotA, sum_a};
+}
+// The pass about to be launched adds the mask-list sums of its rho into slotA: whatever an earlier pass left there unconsumed goes
+static int begin_sum_a(vmr_ctx* h, hipStream_t st) {
+  const Geo& g = h->g;
+  if (!h->a_zero) HIPCHK(h, hipMemsetAsync(h->slotA, 0, (size_t)g.L * NSLOT * g.W * 64 * g.K * 8, st));
+  h->a_zero = false;
+  return VMR_OK;
 }
 // steps of 64 ties per layer / waves per workgroup: at least one step per wave
 static long long sp_grid_cap(const Geo& g, int tpb) {
@@ -2548,9 +2600,10 @@ static int launch_hist(vmr_ctx* h) {
   if (h->sparse) {
     HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));   // (the pass sums rho over all-ones mask rows)
     h->f_valid = g.fuse_full != 0;
+    if (g.ml) { int rc = begin_sum_a(h, h->stream); if (rc) return rc; h->a_valid = true; }
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     const SpShape sh = sp_shape(h, false, false, true);
-    SpArgs a = sp_args(h, sh, 1);
+    SpArgs a = sp_args(h, sh, 1, g.ml);
     int rc = VMR_OK;
     DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc;
                hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
@@ -2589,7 +2642,10 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
   // mask rows that are all ones were already summed by the last rho pass (slotF); the mask kernel then only
   // handles partial rows, and is not needed at all when R has none
   const int skip_full = (g.fuse_full && h->f_valid) ? 1 : 0;
-  if (skip_full && h->n_partial > 0 && h->rq) {   // partial rows only, and they are short lists
+  if (skip_full && h->n_partial > 0 && h->rq && h->a_valid) {
+    // the last rho / statistics pass summed the lists on its way (SpArgs::sum_a): nothing to launch
+  } else if (skip_full && h->n_partial > 0 && h->rq) {   // partial rows only, and they are short lists
+    { int rc = begin_sum_a(h, ms); if (rc) return rc; }
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     const size_t T_ = (size_t)g.N * g.N;
     int gl = (int)std::min<size_t>(std::max<size_t>(1, (size_t)h->ncu / g.L), (T_ + 4 * TPB - 1) / (4 * TPB));
@@ -2633,6 +2689,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg,
                        h->sparse ? h->Fg : nullptr, with_phi ? 1 : 0, consume, g);
     h->ftab_valid = h->sparse && with_phi;
+    h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
     if (consume) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
   }
   HIPCHK(h, hipGetLastError());
@@ -2675,8 +2732,11 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
+    const int sum_a = (g.ml && do_hist) ? 1 : 0;   // (two passes: the statistics pass that follows sums the lists)
+    if (mode != 2) h->a_valid = false;
+    if (sum_a) { if ((rc = begin_sum_a(h, h->stream))) return rc; h->a_valid = true; }
     const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
-    SpArgs s = sp_args(h, sh, do_hist);
+    SpArgs s = sp_args(h, sh, do_hist, sum_a);
 #define LSP(MUT_, UPD_, ELB_)                                                                  \
   DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_>, sh.smem, &s.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
              hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_>), dim3(g.L * s.Gl), dim3(sh.tpb), sh.smem, h->stream, s, g))
@@ -2941,6 +3001,7 @@ static int mask_lists_from_words(vmr_ctx* h) {
 static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
   const int L = g.L, K = g.K;
+  g.ml = (h->sparse && h->rq) ? 1 : 0;
   // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
   g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
   g.yt = 0;
@@ -3506,6 +3567,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   h->have_state = true;
   h->h_valid = false;
   h->f_valid = false;
+  h->a_valid = false;
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   return VMR_OK;
 }
@@ -3526,7 +3588,7 @@ static int sweep(vmr_ctx* h, int mode) {
 // After a committed sweep the handle is in a fixed point of its bookkeeping: the next sweep is the same three or four
 // launches with the same arguments.  Such sweeps are captured once (per count n) and replayed as one graph launch.
 static bool sweep_steady(const vmr_ctx* h) {
-  return h->have_state && h->h_valid && h->h_reduced && !h->h_zero && h->f_valid == (h->g.fuse_full != 0) && !h->prof;
+  return h->have_state && h->h_valid && h->h_reduced && !h->h_zero && h->f_valid == (h->g.fuse_full != 0) && (!h->g.ml || h->a_valid) && !h->prof;
 }
 static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
   for (auto& e : h->graphs) if (e.first == n) { *out = e.second; return VMR_OK; }
@@ -3732,7 +3794,7 @@ int vmr_restore(vmr_handle h) {
   const Geo& g = h->g;
   HIPCHK(h, hipMemcpyAsync(h->rho, h->rho_snap, (size_t)g.L * g.N * g.N * g.K * 8, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->par, h->par_snap, h->par_doubles * 8, hipMemcpyDeviceToDevice, h->stream));
-  h->h_valid = false; h->f_valid = false; h->ftab_valid = false; h->h_zero = false;
+  h->h_valid = false; h->f_valid = false; h->a_valid = false; h->ftab_valid = false; h->h_zero = false;
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
