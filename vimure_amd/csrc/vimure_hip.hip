@@ -1551,6 +1551,44 @@ __device__ __forceinline__ double log_pos(double x) {
   return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
+// Table-driven exp / log for the rho pass (tables in LDS, filled by sp_math_tables): less than half the instructions of the
+// polynomial-only versions, and a shorter dependent chain per tie.
+//   exp_tab(x), |x| < 700:  n = rint(x 64/ln2), r = x - n ln2/64 (|r| <= 0.0055), exp(x) = 2^(n>>6) T[n&63] (1 + r + .. + r^5/120);
+//                            truncation r^6/720 < 4e-17, measured against the library over [-700, 700]: <= 1 ulp
+//   log_tab(x), x > 0 normal: x = 2^k m, m in [0.5, 1), c = midpoint of m's 1/256-wide cell, r = m/c - 1 (|r| <= 2^-8, 1/c tabulated),
+//                            log x = k ln2 + log c + (r - r^2/2 + .. - r^6/6); truncation 2^-56/7: ABSOLUTE error ~2e-16 (what sums of
+//                            ELBO terms need; near x = 1 the relative error is large, unlike log_pos)
+#ifndef SP_TABLE_MATH
+#define SP_TABLE_MATH 1
+#endif
+#define SP_MATH_DOUBLES (64 + 256)
+__device__ __forceinline__ void sp_math_tables(double* xt /*64*/, double* lt /*128 x (1/c, log c)*/, int tid, int nthr) {
+  for (int j = tid; j < 64; j += nthr) xt[j] = exp2((double)j * (1.0 / 64.0));
+  for (int i = tid; i < 128; i += nthr) {
+    const double c = 0.5 + ((double)i + 0.5) * (1.0 / 256.0);
+    lt[2 * i] = 1.0 / c;
+    lt[2 * i + 1] = log(c);
+  }
+}
+__device__ __forceinline__ double exp_tab(double x, const double* xt) {
+  const double nf = __builtin_rint(x * 92.33248261689366);            // 64 / ln 2
+  double r = fma(-nf, 0x1.62e42fee00000p-7, x);                        // ln2/64, upper 32 bits: nf * hi is exact
+  r = fma(-nf, 2.9815858269852933e-12, r);
+  const int n = (int)nf;
+  const double t = xt[n & 63];
+  const double q = r * fma(r, fma(r, fma(r, fma(r, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  return __builtin_amdgcn_ldexp(fma(t, q, t), n >> 6);
+}
+__device__ __forceinline__ double log_tab(double x, const double* lt) {
+  const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  const int k = __builtin_amdgcn_frexp_exp(x);
+  const int i = (__double2hiint(m) >> 13) & 127;
+  const double2 cl = *reinterpret_cast<const double2*>(lt + 2 * i);
+  const double r = fma(m, cl.x, -1.0);
+  const double p = r * fma(r, fma(r, fma(r, fma(r, fma(r, -1.0 / 6.0, 0.2), -0.25), 1.0 / 3.0), -0.5), 1.0);
+  return fma((double)k, 0.6931471805599453, cl.y + p);
+}
+
 // K consecutive doubles of a [.][K] array: 16-byte accesses when K is even (the arrays are 256-byte aligned)
 template <int K>
 __device__ __forceinline__ void load_k(const double* __restrict__ p, double (&v)[K]) {
@@ -1612,6 +1650,8 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   double* As = reinterpret_cast<double*>(smem + off); off += a.sum_a ? (size_t)Mp * K * 8 : 0;   // [Mp][K], see SpArgs::sum_a
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
+  double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;      // exp_tab / log_tab tables
+  double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
   // wave-private, [K][64], for the rest of a step: the ties' sums U, then their new rho (ELBO variants: exp(rho) there and
   // rho in rt)
   double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)nw * 64 * K * 8;
@@ -1626,6 +1666,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
   for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
   if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
+  if (SP_TABLE_MATH && (UPDATE || ELBO)) sp_math_tables(xt, lt, tid, nthr);
   if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
   const double* lut = a.lutg + (size_t)l * g.W * 256;
   for (int w = tid; w < g.W; w += nthr) {
@@ -1742,7 +1783,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
       for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
     }
-    e_log += dx * log_pos(inner + eps);
+    e_log += dx * (SP_TABLE_MATH ? log_tab(inner + eps, lt) : log_pos(inner + eps));
   };
 
   // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749).  Lanes of a
@@ -1803,7 +1844,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        if (ELBO) er[k] = exp(r[k]);
+        if (ELBO) er[k] = SP_TABLE_MATH ? exp_tab(r[k], xt) : exp(r[k]);   // (rho in [0, 1])
         if (has_rest) {   // the rest's reports look their tie up in LDS: slot 0 = dfc, categories 1.. as they are
           rt[k * 64 + lane] = (k == 0) ? dfc : r[k];
           if (ELBO) ut[k * 64 + lane] = er[k];
@@ -1936,7 +1977,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         const double d = aa[1] - aa[0];
         const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
         if (__all(safe)) {
-          const double e = (g.dbg & 64) ? d : exp(d);   // (timing experiment: no exp)
+          const double e = (g.dbg & 64) ? d : (SP_TABLE_MATH ? exp_tab(d, xt) : exp(d));   // (dbg 64: timing experiment, no exp)
           r[0] = 1.0 / (1.0 + e);
           r[1] = e * r[0];
           done = true;
@@ -1944,8 +1985,19 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
       }
       if (!done) {
         double sum = 0.0;
+        bool tame = SP_TABLE_MATH != 0;   // every a_k of the wave's ties where exp neither overflows nor underflows (else: the library's)
 #pragma unroll
-        for (int k = 0; k < K; ++k) { r[k] = exp(aa[k]); sum += r[k]; }   // no max-subtraction, as model.py:807
+        for (int k = 0; k < K; ++k) tame = tame && fabs(aa[k]) < 700.0;
+        tame = __all(tame);
+        if (tame) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] = exp_tab(aa[k], xt);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] = exp(aa[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum += r[k];   // no max-subtraction, as model.py:807
         if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
 #pragma unroll
           for (int k = 0; k < K; ++k) r[k] /= sum;
@@ -2010,7 +2062,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
             for (int j = 0; j < QB; ++j) {
               const unsigned x = ENT_X(pe[j]);
-              const double lg = log_pos(in_[j]);
+              const double lg = SP_TABLE_MATH ? log_tab(in_[j], lt) : log_pos(in_[j]);
               e_log += x != 0u ? (double)x * lg : 0.0;
             }
           }
@@ -2037,7 +2089,7 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         sr += r[k]; se += r[k] * Ela[k];
-        en += r[k] * lp[k] - r[k] * log_pos(r[k] + eps);   // model.py:1306-1313
+        en += r[k] * lp[k] - r[k] * (SP_TABLE_MATH ? log_tab(r[k] + eps, lt) : log_pos(r[k] + eps));   // model.py:1306-1313
       }
       e_lin += en - se * Tt;
       if (MUT) e_q += sr * (double)qt;
@@ -2476,7 +2528,7 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
 static size_t shmem_sp(const Geo& g, int tpb, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
   return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)g.W * 8 + 128 +
-         (g.ml ? lb : 0) +
+         (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 +
          (size_t)(tpb / 64) * 64 * g.K * 8 * (elbo ? 2 : 1) + 16;
 }
 #define SP_LDS_MAX (160 * 1024)
