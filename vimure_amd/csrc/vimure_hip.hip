@@ -1631,7 +1631,7 @@ __device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v
 // Prefetch depth of a variant: as deep as its registers allow without spilling (128 VGPRs at 4 waves/SIMD; the ELBO
 // variants and many categories carry more state per tie)
 __host__ __device__ constexpr int sp_pf(int K, bool elbo) {
-  return elbo ? (K <= 2 ? SP_PF_ELBO2 : (K <= 4 ? 4 : 3)) : (K <= 5 ? SP_PF : 4);
+  return elbo ? (K <= 2 ? SP_PF_ELBO2 : (K == 3 ? 6 : (K == 4 ? 4 : 3))) : (K <= 5 ? SP_PF : 4);
 }
 template <int K, bool MUT, bool UPDATE, bool ELBO>
 __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
