@@ -137,7 +137,7 @@ def test_config3_full_size_fit_stops_where_the_oracle_stops():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mode", ["default", "one_pass_two_levels", "two_passes", "no_lds_levels"])
+@pytest.mark.parametrize("mode", ["default", "short_step_kernels", "one_pass_two_levels", "two_passes", "no_lds_levels"])
 def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): a level of the factor
     table F or of the statistics H is 24 KB here, so only a few levels of each fit in LDS beside each other.  The engine
@@ -147,7 +147,8 @@ def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
-    env = {"one_pass_two_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "2", "VMR_HC": "2"},
+    env = {"short_step_kernels": {"VMR_LONG": "0"},   # (19 reports per tie: the LONG variants of k_rho_sp by default)
+           "one_pass_two_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "2", "VMR_HC": "2"},
            "two_passes": {"VMR_TWO_PASS": "1", "VMR_YT": "5", "VMR_HC": "5"},
            "no_lds_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "0", "VMR_HC": "0", "VMR_TPB": "256"}}.get(mode, {})
     for k, v in env.items():
@@ -172,3 +173,31 @@ def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     eng.close()
     del net
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mask", ["ones", "random"])
+def test_long_steps_two_categories(mask, monkeypatch):
+    """Many reports per tie (here 19 of M = 64 reporters, K = 2): steps of more full rounds than prefetched trips, i.e. the LONG
+    variants of k_rho_sp with their ring of loads -- against the coordinate-list oracle, mutuality on, with and without mask."""
+    from oracle import cavi_coo
+    from vimure_amd import CaviEngine
+    monkeypatch.setenv("VMR_FORMAT", "sparse")   # (at this density the dense tiles would be chosen)
+    L, N, M, K = 2, 150, 64, 2
+    g = np.random.RandomState(11)
+    X = ((g.rand(L, N, N, M) < 0.3) * g.randint(1, 4, size=(L, N, N, M))).astype(np.uint8)
+    R = None if mask == "ones" else (g.rand(L, N, N, M) < 0.7).astype(np.uint8)
+    eng = CaviEngine(X, R, K=K, mutuality=True, device=0)
+    assert eng.data_format()[0] == "sparse"
+    sum_x, cov = eng.data_stats()
+    init = _host_state(L, N, M, K, True, 5, sum_x, cov)
+    sx = np.nonzero(X)
+    c = cavi_coo.CooRef((sx, X[sx]), None if R is None else np.nonzero(R), (L, N, N, M), K, True, PRI, *init)
+    eng.set_priors(*PRI)
+    eng.set_state(*init)
+    for it in range(1, 4):
+        c.cavi_step()
+        e = eng.step(1, want_elbo=True)
+        e_cpu = c.elbo()
+        assert abs(e - e_cpu) <= 1e-9 * abs(e_cpu), (it, e, e_cpu)
+    _assert_state(eng.get_state(), c, e, e_cpu)
+    eng.close()

@@ -38,13 +38,19 @@ def main():
     host, pr = draw_state(cfg, 1, sum_x, cov)
     eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
     eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
-    e1 = eng.step(1, want_elbo=True)
+    try:
+        e1 = eng.step(1, want_elbo=True)
+    except ValueError:   # (timing experiments with VMR_DEBUG give wrong numbers, possibly NaN)
+        e1 = float("nan")
     eng.profile(True)
     t0 = time.perf_counter()
     eng.step(a.steps)
     eng.sync()
     dt = time.perf_counter() - t0
-    eng.step(1, want_elbo=True)   # (outside the timed sweeps: the ELBO variant of the rho pass, for the per-kernel table)
+    try:
+        eng.step(1, want_elbo=True)   # (outside the timed sweeps: the ELBO variant of the rho pass, for the per-kernel table)
+    except ValueError:
+        pass
     prof = eng.profile_read()
     out = {"shape": [1, a.N, a.N, a.M], "K": a.K, "nnz": nnz, "sweeps_per_s": a.steps / dt, "ms_per_sweep": 1e3 * dt / a.steps,
            "elbo_after_1": e1,

@@ -125,6 +125,7 @@ struct vmr_ctx {
   bool h_valid = false;        // H matches the current rho
   double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
   bool f_valid = false;        // slotF matches the current rho
+  bool long_steps = false;     // report lists with >= 8 reports per tie on average: the LONG variants of k_rho_sp
   bool a_valid = false;        // slotA holds the mask-list sums of the current rho (summed by the last rho / statistics pass)
   bool a_zero = true;          // slotA is known to be all zero
   bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
@@ -1197,6 +1198,9 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 #ifndef SP_PF_ELBO2
 #define SP_PF_ELBO2 6
 #endif
+#ifndef SP_LONG_KMAX
+#define SP_LONG_KMAX 4   // the LONG variants of k_rho_sp are compiled for K <= this (compile time)
+#endif
 #ifndef SP_QB
 #define SP_QB 3   // of those, the trips the common step takes in one batch (k_rho_sp's "quick" path); <= SP_PF.  (Batching all
                   // full rounds among the prefetched trips, 4 or 5 at a time, was measured slower: fewer steps qualify.)
@@ -1319,6 +1323,8 @@ __global__ __launch_bounds__(256) void k_sp_round(const unsigned* __restrict__ r
     const unsigned r0 = rpl[ok ? t : T], n = rpl[ok ? t + 1 : T] - r0;
     const unsigned ea = rsl[2 * s], et = rsl[2 * s + 1];
     const unsigned R = (et - ea) >> 6;
+    // (Rotating each tie's reports by a per-tie offset, so that a round does not hold the r-th smallest reporter of all its 64
+    // ties -- neighbouring LDS addresses -- was tried: no gain, -2 % at config 3.)
     for (unsigned r = 0; r < R; ++r) Eout[(size_t)ea + r * 64 + lane] = n > r ? Ein[(size_t)r0 + r] : 0u;
     unsigned nmax = n;
 #pragma unroll
@@ -1633,10 +1639,13 @@ __device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v
 __host__ __device__ constexpr int sp_pf(int K, bool elbo) {
   return elbo ? (K <= 2 ? SP_PF_ELBO2 : (K == 3 ? 6 : (K == 4 ? 4 : 3))) : (K <= 5 ? SP_PF : 4);
 }
-template <int K, bool MUT, bool UPDATE, bool ELBO>
+// LONG: the variant for datasets of long steps (many reports per tie, see the ring below); it carries 12 registers more and
+// costs 3 % on short-step data, so it is a variant of its own, chosen per dataset (vmr_ctx::long_steps), compiled for K <= 4.
+template <int K, bool MUT, bool UPDATE, bool ELBO, bool LONG = false>
 __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PF = sp_pf(K, ELBO), QB = SP_QB < PF ? SP_QB : PF;   // prefetched trips per step; trips of the batched path
+  constexpr int RG = LONG ? 8 : 1;                                   // loads in flight in the further full rounds of a long step
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int Mp = g.Mp;
@@ -1825,6 +1834,29 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
     for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
 #pragma unroll
     for (int j = 0; j < PF; ++j) pe[j] = pen[j];
+    // Long steps (more full rounds than prefetched trips; a config-5 layer has 19 reports per tie): their further full rounds
+    // keep RG loads in flight -- issued RG trips ahead of their use, the first RG here at the top of the step; prefetching one
+    // trip ahead left every trip waiting for memory -- and take a body without the rest's bookkeeping.
+    unsigned rg[RG];
+    auto ring_fill = [&]() {
+#pragma unroll
+      for (int i = 0; i < RG; ++i) rg[i] = (PF + i < R) ? El[(size_t)ea + (unsigned)lane + (unsigned)(PF + i) * 64] : 0u;
+    };
+    auto ring_walk = [&](auto&& body) {
+      for (int j0 = PF; j0 < R; j0 += RG) {
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+          if (j0 + i < R) {   // (wave-uniform)
+            const unsigned cur = rg[i];
+            const int jn = j0 + i + RG;
+            rg[i] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
+            body(cur);
+          }
+        }
+      }
+    };
+    const int jr = (LONG && R > PF) ? R : PF;   // first trip of the one-ahead loops below: the rest of a long step
+    if (LONG && R > PF) ring_fill();
     if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
@@ -1949,10 +1981,20 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         for (int j = 0; j < PF; ++j) {
           if ((j >= QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
         }
-        if (trips1 > PF) {   // long steps: rolling prefetch one trip ahead
-          unsigned q = (unsigned)lane + (unsigned)PF * 64;
+        if (LONG && R > PF && trips1 > 0) {
+          ring_walk([&](unsigned ent) {
+            double f[K];
+            f_row(ENT_YM(ent), f, near);
+            const double dx = (double)ENT_X(ent);
+#pragma unroll
+            for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
+          });
+          if (a.do_hist || ELBO) ring_fill();   // (walk 2 goes over the same trips: from the L2 now)
+        }
+        if (trips1 > jr) {   // the rest of a long step: one trip ahead
+          unsigned q = (unsigned)lane + (unsigned)jr * 64;
           unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = PF; j < trips; ++j) {
+          for (int j = jr; j < trips; ++j) {
             const unsigned cur = nx;
             q += 64;
             nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
@@ -2071,10 +2113,21 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
         for (int j = 0; j < PF; ++j) {
           if ((j >= QB || !quick2) && j < trips) trip2(pe[j], j, near);
         }
-        if (trips > PF) {
-          unsigned q = (unsigned)lane + (unsigned)PF * 64;
+        if (LONG && R > PF) {
+          ring_walk([&](unsigned ent) {   // this lane's own tie
+            const unsigned ym = ENT_YM(ent);
+            const double dx = (double)ENT_X(ent);
+            double xr[K];
+#pragma unroll
+            for (int k = 1; k < K; ++k) xr[k] = dx * r[k];
+            if (a.do_hist) h_add(ym, xr, irr ? dx * dfc : 0.0, ENT_X(ent) != 0u, near);
+            if (ELBO) elbo_log(ent, ym, dx, er);
+          });
+        }
+        if (trips > jr) {
+          unsigned q = (unsigned)lane + (unsigned)jr * 64;
           unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = PF; j < trips; ++j) {
+          for (int j = jr; j < trips; ++j) {
             const unsigned cur = nx;
             q += 64;
             nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
@@ -2657,8 +2710,11 @@ static int launch_hist(vmr_ctx* h) {
     const SpShape sh = sp_shape(h, false, false, true);
     SpArgs a = sp_args(h, sh, 1, g.ml);
     int rc = VMR_OK;
-    DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc;
-               hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
+#define LHIST(LG_)                                                                                                                     \
+  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false, ((LG_) && KK <= SP_LONG_KMAX)>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
+             hipLaunchKernelGGL((k_rho_sp<KK, false, false, false, ((LG_) && KK <= SP_LONG_KMAX)>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g))
+    if (h->long_steps) { LHIST(true); } else { LHIST(false); }
+#undef LHIST
   } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     HistArgs a{h->X, h->rho, h->Hg, 1};
@@ -2789,15 +2845,17 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     if (sum_a) { if ((rc = begin_sum_a(h, h->stream))) return rc; h->a_valid = true; }
     const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
     SpArgs s = sp_args(h, sh, do_hist, sum_a);
-#define LSP(MUT_, UPD_, ELB_)                                                                  \
-  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_>, sh.smem, &s.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
-             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_>), dim3(g.L * s.Gl), dim3(sh.tpb), sh.smem, h->stream, s, g))
+#define LSP2(MUT_, UPD_, ELB_, LG_)                                                            \
+  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_, ((LG_) && KK <= SP_LONG_KMAX)>, sh.smem, &s.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
+             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_, ((LG_) && KK <= SP_LONG_KMAX)>), dim3(g.L * s.Gl), dim3(sh.tpb), sh.smem, h->stream, s, g))
+#define LSP(MUT_, UPD_, ELB_) do { if (h->long_steps) { LSP2(MUT_, UPD_, ELB_, true); } else { LSP2(MUT_, UPD_, ELB_, false); } } while (0)
     if (g.mut) {
       if (mode == 0) { LSP(true, true, false); } else if (mode == 1) { LSP(true, true, true); } else { LSP(true, false, true); }
     } else {
       if (mode == 0) { LSP(false, true, false); } else if (mode == 1) { LSP(false, true, true); } else { LSP(false, false, true); }
     }
 #undef LSP
+#undef LSP2
   } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
@@ -3054,6 +3112,8 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
   const int L = g.L, K = g.K;
   g.ml = (h->sparse && h->rq) ? 1 : 0;
+  h->long_steps = h->sparse && (double)h->nnz >= 8.0 * (double)g.L * (double)g.N * (double)g.N;
+  if (const char* e = getenv("VMR_LONG")) h->long_steps = h->sparse && atoi(e) != 0;
   // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
   g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
   g.yt = 0;
