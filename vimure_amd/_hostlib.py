@@ -34,7 +34,7 @@ _pool = None
 
 def _threads():
     global _pool
-    n = max(1, min(16, os.cpu_count() or 1))
+    n = max(1, min(32, os.cpu_count() or 1))
     if _pool is None and n > 1:
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="vmr-draw")
@@ -66,10 +66,8 @@ def draw_pr_rho(prng, shape, bias0, coverage, out=None, threads=None):
     flat = out.reshape(-1)
     cov = None if coverage is None else np.ascontiguousarray(coverage, dtype=np.uint8).reshape(-1)
 
-    def block(t0, t1):   # ties [t0, t1): skip to the block's first word, draw
-        key, pos = key0.copy(), C.c_int(pos0)
-        if t0:
-            lib.vmr_host_mt_skip(key.ctypes.data, C.byref(pos), 2 * K * t0)
+    def draw(key, pos, t0, t1):   # ties [t0, t1) from the generator state (key, pos) at the block's first word
+        pos = C.c_int(pos)
         lib.vmr_host_draw_pr_rho(key.ctypes.data, C.byref(pos), t1 - t0, K, float(bias0),
                                  None if cov is None else cov[t0:].ctypes.data, flat[t0 * K:].ctypes.data)
         return key, pos.value
@@ -77,14 +75,36 @@ def draw_pr_rho(prng, shape, bias0, coverage, out=None, threads=None):
     nthr, pool = _threads()
     if threads is not None:
         nthr = max(1, min(nthr, int(threads)))
-    if ties * K < (1 << 20) or pool is None:
+    if ties * K < (1 << 20) or pool is None or nthr < 3:
         nthr = 1
     if nthr == 1:
-        key, pos = block(0, ties)
+        key, pos = draw(key0.copy(), pos0, 0, ties)
     else:
-        cuts = [ties * i // nthr for i in range(nthr + 1)]
-        futs = [pool.submit(block, cuts[i], cuts[i + 1]) for i in range(nthr)]
-        res = [f.result() for f in futs]
-        key, pos = res[-1]   # the last block ends where the whole draw ends
+        # One thread walks the generator from block to block WITHOUT producing numbers (the skip is a sequential chain: 64 M
+        # words take 11 ms whoever does them) and publishes each block's state as it reaches it; the other threads draw the
+        # blocks as their states arrive.  (Each block skipping from the start on its own cost the last one the whole chain
+        # before its first number.)
+        import threading
+        nblk = int(min(512, max(nthr, ties * K >> 19)))
+        cuts = [ties * i // nblk for i in range(nblk + 1)]
+        states, ready, ends = [None] * nblk, [threading.Event() for _ in range(nblk)], [None] * nblk
+
+        def skipper():
+            key, pos = key0.copy(), C.c_int(pos0)
+            for b in range(nblk):
+                states[b] = (key.copy(), pos.value)
+                ready[b].set()
+                if b + 1 < nblk:
+                    lib.vmr_host_mt_skip(key.ctypes.data, C.byref(pos), 2 * K * (cuts[b + 1] - cuts[b]))
+
+        def worker(w, nw):
+            for b in range(w, nblk, nw):
+                ready[b].wait()
+                ends[b] = draw(states[b][0], states[b][1], cuts[b], cuts[b + 1])
+
+        futs = [pool.submit(skipper)] + [pool.submit(worker, w, nthr - 1) for w in range(nthr - 1)]
+        for f in futs:
+            f.result()
+        key, pos = ends[-1]   # the last block ends where the whole draw ends
     prng.set_state(("MT19937", key, pos, st[3], st[4]))
     return out.reshape(shape)
