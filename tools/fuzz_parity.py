@@ -52,8 +52,15 @@ def one(case, g):
     os.environ.update(env)
     desc = f"case {case}: L{L} N{N} M{M} K{K} mut={int(mut)} dens={dens} xmax={xmax} mask={mk} env={env}"
     try:
+        use_coo = fmt != "dense" and xmax <= 63 and M <= 8192 and g.rand() < 0.4   # the coordinate-list entry point (vmr_create_coo)
+        if use_coo:
+            desc += " [coo]"
         try:
-            eng = CaviEngine(X, R, K=K, mutuality=mut, device=0)
+            if use_coo:
+                sx0 = np.nonzero(X)
+                eng = CaviEngine.from_coo(sx0, X[sx0], X.shape, R=None if R is None else np.nonzero(R), K=K, mutuality=mut, device=0)
+            else:
+                eng = CaviEngine(X, R, K=K, mutuality=mut, device=0)
         except ValueError as e:   # a refused combination (e.g. sparse forced with counts the lists cannot hold)
             print(desc, "-> refused:", str(e)[:80], flush=True)
             return True
