@@ -143,7 +143,27 @@ class CaviEngine:
             self._staging.append(host_buffer(self.L * self.N * self.N * self.K))
         return self._staging[i][0].reshape(self.L, self.N, self.N, self.K)
 
+    def upload_ahead(self, i, slot):
+        """Copy staging buffer i to a device buffer of this engine (two in rotation: `slot` 0 / 1) on a stream of its own and
+        wait for the copy; returns the device tensor (what `set_state` then takes with a device-to-device copy), or None
+        when the staging buffer is not page-locked / torch is not there.  For the thread that draws the next realisation
+        while the GPU sweeps the current one: the 5 ms upload of a 256 MB pr_rho leaves the critical path."""
+        arr, ten = self._staging[i]
+        if ten is None:
+            return None
+        import torch
+        if not hasattr(self, "_ahead"):
+            self._ahead = [None, None]
+            self._ahead_stream = torch.cuda.Stream(device=self.device)
+        if self._ahead[slot] is None:
+            self._ahead[slot] = torch.empty((self.L, self.N, self.N, self.K), dtype=torch.float64, device=f"cuda:{self.device}")
+        with torch.cuda.stream(self._ahead_stream):
+            self._ahead[slot].view(-1).copy_(ten, non_blocking=True)
+        self._ahead_stream.synchronize()
+        return self._ahead[slot]
+
     def close(self):
+        self._ahead = [None, None]
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.vmr_destroy(self._h)
             self._h = C.c_void_p()
@@ -178,7 +198,8 @@ class CaviEngine:
             assert pr_rho.is_cuda and pr_rho.is_contiguous() and tuple(pr_rho.shape) == (self.L, self.N, self.N, self.K)
             import torch
             assert pr_rho.dtype == torch.float64
-            torch.cuda.synchronize(pr_rho.device)
+            if not any(pr_rho is t for t in getattr(self, "_ahead", [])):   # (upload_ahead has waited for its copy already)
+                torch.cuda.synchronize(pr_rho.device)
             pp, dev = pr_rho.data_ptr(), 1
         else:
             pr_rho = _f64(pr_rho)

@@ -300,6 +300,12 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 def work():
                     try:
                         for item in states:
+                            r_ = item[0]
+                            pr_ = item[2]["pr_rho"]
+                            if r_ > 0 and isinstance(pr_, np.ndarray) and np.shares_memory(pr_, eng.staging(r_ % 3)):
+                                dev = eng.upload_ahead(r_ % 3, r_ % 2)   # (realisation 0 is waited for: nothing to hide its upload behind)
+                                if dev is not None:
+                                    item[2]["pr_rho"] = dev
                             q.put(item)
                         q.put(None)
                     except BaseException as e:   # surfaces in the consumer
