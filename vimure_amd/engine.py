@@ -143,6 +143,13 @@ class CaviEngine:
             self._staging.append(host_buffer(self.L * self.N * self.N * self.K))
         return self._staging[i][0].reshape(self.L, self.N, self.N, self.K)
 
+    def can_upload_ahead(self):
+        """Page-locked staging buffers (through torch) exist for this engine's rho size, i.e. `upload_ahead` works."""
+        if not hasattr(self, "_can_ahead"):
+            self.staging(0)
+            self._can_ahead = self._staging[0][1] is not None
+        return self._can_ahead
+
     def upload_ahead(self, i, slot):
         """Copy staging buffer i to a device buffer of this engine (two in rotation: `slot` 0 / 1) on a stream of its own and
         wait for the copy; returns the device tensor (what `set_state` then takes with a device-to-device copy), or None

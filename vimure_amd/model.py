@@ -241,6 +241,13 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 setattr(self, k, v)
         return st
 
+    def _staging_index(self, eng, r):
+        """Which pinned staging buffer realisation r is drawn into: with upload-ahead (see fit) buffer 1 is free again as soon as
+        its copy to the device is done, so two buffers serve any number of realisations; otherwise three in rotation."""
+        if self.num_realisations > 1 and getattr(eng, "can_upload_ahead", lambda: False)():
+            return 0 if r == 0 else 1
+        return r % 3
+
     def _initial_states(self, eng, coverage):
         """Initial state of every realisation, in order: (r, seed of r, state dict incl. pr_rho, seed after r).  CAVI
         consumes no randomness (reference model.py:386-437), so the whole seed chain is a function of the first seed
@@ -249,7 +256,7 @@ class VimureModel(TransformerMixin, BaseEstimator):
         seed, prng = self.seed, self.prng
         for r in range(self.num_realisations):
             bias = DEFAULT_BIAS0 if r < 5 else (r - 4) * self.bias0
-            pr = self._draw_pr_rho(coverage, bias, prng=prng, out=eng.staging(r % 3))
+            pr = self._draw_pr_rho(coverage, bias, prng=prng, out=eng.staging(self._staging_index(eng, r)))
             st = self._draw_gammas(self.sumX, prng=prng)
             st["pr_rho"] = pr
             step = prng.randint(1, 500)
@@ -302,8 +309,9 @@ class VimureModel(TransformerMixin, BaseEstimator):
                         for item in states:
                             r_ = item[0]
                             pr_ = item[2]["pr_rho"]
-                            if r_ > 0 and isinstance(pr_, np.ndarray) and np.shares_memory(pr_, eng.staging(r_ % 3)):
-                                dev = eng.upload_ahead(r_ % 3, r_ % 2)   # (realisation 0 is waited for: nothing to hide its upload behind)
+                            si = self._staging_index(eng, r_)
+                            if r_ > 0 and getattr(eng, "can_upload_ahead", lambda: False)() and isinstance(pr_, np.ndarray) and np.shares_memory(pr_, eng.staging(si)):
+                                dev = eng.upload_ahead(si, r_ % 2)   # (realisation 0 is waited for: nothing to hide its upload behind)
                                 if dev is not None:
                                     item[2]["pr_rho"] = dev
                             q.put(item)
