@@ -1982,13 +1982,59 @@ __global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs
           if ((j >= QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
         }
         if (LONG && R > PF && trips1 > 0) {
-          ring_walk([&](unsigned ent) {
+          auto single = [&](unsigned ent) {
             double f[K];
             f_row(ENT_YM(ent), f, near);
             const double dx = (double)ENT_X(ent);
 #pragma unroll
             for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
-          });
+          };
+          // groups of GB trips whose rows are all in the LDS levels: their table reads are issued back to back (one LDS latency
+          // per group, as in the batched path of the prefetched trips)
+          constexpr int GB = K <= 2 ? 4 : 2;
+          for (int j0 = PF; j0 < R; j0 += RG) {
+#pragma unroll
+            for (int gi = 0; gi < RG; gi += GB) {
+              if (j0 + gi + GB - 1 < R) {   // (wave-uniform)
+                unsigned c[GB];
+                bool far = false;
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                  c[u] = rg[gi + u];
+                  const int jn = j0 + gi + u + RG;
+                  rg[gi + u] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
+                  far = far || ENT_YM(c[u]) >= ytm;
+                }
+                if (decltype(near)::value || !__any(far)) {
+                  double f[GB][K];
+#pragma unroll
+                  for (int u = 0; u < GB; ++u) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) f[u][k] = F[ENT_YM(c[u]) * K + k];
+                  }
+#pragma unroll
+                  for (int u = 0; u < GB; ++u) {
+                    const double dx = (double)ENT_X(c[u]);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) U[k] = fma(dx, f[u][k], U[k]);
+                  }
+                } else {
+#pragma unroll
+                  for (int u = 0; u < GB; ++u) single(c[u]);
+                }
+              } else {
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                  if (j0 + gi + u < R) {
+                    const unsigned cur = rg[gi + u];
+                    const int jn = j0 + gi + u + RG;
+                    rg[gi + u] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
+                    single(cur);
+                  }
+                }
+              }
+            }
+          }
           if (a.do_hist || ELBO) ring_fill();   // (walk 2 goes over the same trips: from the L2 now)
         }
         if (trips1 > jr) {   // the rest of a long step: one trip ahead
