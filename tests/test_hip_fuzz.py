@@ -1,7 +1,7 @@
 """GPU: randomised parity sweep -- random shapes (N, M not multiples of anything), K in 2..8, mutuality on/off, every mask kind,
 count ranges up to 63, both data layouts and forced engine shapes (table levels, one / two passes, workgroup sizes, LONG and
-short-step kernels) -- three sweeps with the ELBO each against the coordinate-list oracle (tools/fuzz_parity.py; 500 further cases
-were run by hand at the end of round 2: no mismatch).  A case in which the ELBO is NaN must be NaN in the oracle too."""
+short-step kernels) -- three sweeps with the ELBO each against the coordinate-list oracle (tools/fuzz_parity.py; 2 000 further
+cases were run by hand at the end of round 2: no mismatch).  A case in which the ELBO is NaN must be NaN in the oracle too."""
 import numpy as np
 import pytest
 
