@@ -2317,6 +2317,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   __shared__ double lla_n[KMAX], gla_n[KMAX];   // the new E[log lambda], G_lambda (for the factor table F)
+  __shared__ double bsum[2 * KMAX], prte_n[KMAX];
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
   if (tid < K) {
@@ -2383,20 +2384,26 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
     gthn[m] = gn;
     for (int k = 0; k < K; ++k) pr[k] += e * A[k];
   }
+  // the K sums first, then one thread per category finishes its lambda_k (digamma, log, exp and the parameter loads of the K
+  // categories side by side instead of one after the other in thread 0)
   for (int k = 0; k < K; ++k) {
     double v = block_sum_fin(pr[k], red);
     double ps = g.mut ? 0.0 : block_sum_fin(p0[k], red);   // mutuality off: phi_shp = alpha + sum x rho_k (model.py:861-887)
-    if (tid == 0) {
-      double rte = par[o.b_la + l * K + k] + v;
-      if (g.mut) {
-        par[o.p_rte_pend + l * K + k] = rte;
-      } else {
-        double shp = par[o.a_la + l * K + k] + ps;
-        par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
-        double lg = digamma_pos(shp) - log(rte);
-        par[o.E_la + l * K + k] = shp / rte; par[o.l_la + l * K + k] = lg; par[o.G_la + l * K + k] = exp(lg);
-        lla_n[k] = lg; gla_n[k] = exp(lg);
-      }
+    if (tid == 0) { bsum[k] = v; bsum[KMAX + k] = ps; }
+  }
+  __syncthreads();
+  if (tid < K) {
+    const int k = tid;
+    double rte = par[o.b_la + l * K + k] + bsum[k];
+    if (g.mut) {
+      par[o.p_rte_pend + l * K + k] = rte;
+      prte_n[k] = rte;
+    } else {
+      double shp = par[o.a_la + l * K + k] + bsum[KMAX + k];
+      par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
+      double lg = digamma_pos(shp) - log(rte);
+      par[o.E_la + l * K + k] = shp / rte; par[o.l_la + l * K + k] = lg; par[o.G_la + l * K + k] = exp(lg);
+      lla_n[k] = lg; gla_n[k] = exp(lg);
     }
   }
   // (fused sweep) phi right away: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887),
@@ -2417,14 +2424,16 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
     }
     for (int k = 0; k < K; ++k) {
       double v = block_sum_fin(ps[k], red);
-      if (tid == 0) {
-        const int q = l * K + k;
-        double shp = par[o.a_la + q] + v, rte = par[o.p_rte_pend + q];
-        par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
-        double lg = digamma_pos(shp) - log(rte);
-        par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
-        lla_n[k] = lg; gla_n[k] = exp(lg);
-      }
+      if (tid == 0) bsum[k] = v;
+    }
+    __syncthreads();
+    if (tid < K) {
+      const int k = tid, q = l * K + k;
+      double shp = par[o.a_la + q] + bsum[k], rte = prte_n[k];   // (phi_rte as computed above, also in p_rte_pend)
+      par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
+      double lg = digamma_pos(shp) - log(rte);
+      par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+      lla_n[k] = lg; gla_n[k] = exp(lg);
     }
   }
   // (fused sweep, report lists) the factor table F of the rho pass from the new theta, lambda and the current nu
