@@ -1,5 +1,6 @@
+"""Histogram of mirror-count levels and count values of a config-5-regime layer (development aid, GPU box)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vimure_amd.synthetic import standard_sbm
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 net = standard_sbm(N=N, M=1000, L=1, K=3, C=2, avg_degree=5.0, eta=0.5, seed=0, device="cuda:0")

@@ -1,5 +1,6 @@
+"""Time of the bit-exact RandomState draw of pr_rho on the host by thread count (development aid)."""
 import numpy as np, time, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vimure_amd import _hostlib
 print("cpus", os.cpu_count(), len(os.sched_getaffinity(0)))
 shape = (4, 2000, 2000, 2)

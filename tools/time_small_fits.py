@@ -1,5 +1,6 @@
+"""Karnataka-shaped small fits: time per sweep, per kernel and per fit on one engine (development aid, GPU box)."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 warnings.simplefilter("ignore")
 from vimure_amd import CaviEngine, VimureModel
