@@ -5,6 +5,16 @@
   python bench.py --gpus N --steps K --warmup W
   (N>1: launched by torch.distributed.run, one rank per GPU; weak scaling: every rank fits the
    same dataset from its own seed, the only collective is the final gather of ELBOs over RCCL)
+  python bench.py --config c5 --gpus 8     BASELINE configs[4]: ONE fit of 8 layers N=8000 M=1000 K=3, one layer per rank
+                                           (vimure_amd.sharded: a 3-double RCCL all-reduce per sweep); metric = sweeps/s
+  python bench.py --config c4 --gpus N     BASELINE configs[3]: Karnataka-shaped villages x 4 layers x seeds sharded over the
+                                           ranks (vimure_amd.batch.fit_datasets(dist=...)); metric = fits/s
+  Both refuse (exit code 2) on a node with fewer GPUs than asked for.
+
+The timed block of K steps is repeated REPEATS times inside the run; `value` is the median block (min / max in
+`timing_blocks`).  After the timed region, under a time budget, the default run adds two blocks measured on the same GPU:
+`c5_layer` (one layer of configs[4] at its stated size: ms per sweep, per-kernel rates) and `small_fits` (the configs[3]
+workload of tools/bench_batch.py: fits/s from ONE process).
 
 A "step" is one full CAVI sweep (gamma, phi, rho, nu: reference model.py:623-660) with the ELBO
 evaluated at the reference cadence (iteration 1 and every 10th, model.py:1036).  Inputs are
@@ -61,7 +71,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4", "c5"])
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps sweeps; value = the median block")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c5_layer / small_fits blocks after the timed region")
+    ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra blocks")
+    ap.add_argument("--villages", type=int, default=16, help="--config c4: synthetic villages (x 4 layers x --seeds fits)")
+    ap.add_argument("--seeds", type=int, default=3, help="--config c4: seeds per (village, layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (bounded sample)")
     ap.add_argument("--format", default="auto", choices=["auto", "dense", "sparse"],
@@ -87,6 +102,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    if world > 1 and rank == 0:
+        print(f"bench.py: RCCL world size {dist.get_world_size()} (backend {dist.get_backend()}), one rank per GPU", file=sys.stderr, flush=True)
+    if args.config == "c5":
+        return bench_c5_sharded(args, rank, world, local, dev, dist)
+    if args.config == "c4":
+        return bench_c4_batch(args, rank, world, local, dev, dist)
 
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
@@ -127,24 +149,32 @@ def main():
     run(1, args.warmup)
     eng.sync()
     eng.profile(True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    elbo = run(args.warmup + 1, args.steps)
-    eng.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    blocks = []
+    elbo = None
+    it0 = args.warmup + 1
+    for _ in range(max(1, args.repeats)):   # every block: barrier + synchronize, EXACTLY --steps sweeps, synchronize + barrier
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e_ = run(it0, args.steps)
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        blocks.append(time.perf_counter() - t0)
+        elbo = e_ if e_ is not None else elbo
+        it0 += args.steps
+    if dist is not None:   # MAX over ranks, block by block
+        tt = torch.tensor(blocks, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        blocks = [float(v) for v in tt.tolist()]
+    dt = float(np.median(blocks))
     prof = eng.profile_read()
     eng.profile(False)
     if elbo is None:
         elbo = eng.elbo()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         # the path's only exchange: gather the per-fit ELBOs (RCCL over xGMI)
         mine = torch.tensor([elbo], dtype=torch.float64, device=dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
@@ -179,7 +209,10 @@ def main():
                        "data_format": "report lists (4 B per non-zero count)" if fmt == "sparse" else "dense u8 tiles",
                        "elbo_cadence": "iter 1 and every 10th (fused into the rho pass)", "parallelism": f"fits x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, "
+                                           "collected in separate --pmc passes; not re-measured in this run)",
+                         "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                          "byte_model": ("report lists: 4 B x nnz(X) + 4 B x ties + log-prior read + rho write"
                                         if fmt == "sparse" else "dense: X 1 B/elt + R 1 bit/elt + log-prior read + rho write")},
@@ -187,6 +220,8 @@ def main():
                             "GBps": (v["bytes_per_launch"] / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9)
                             if v["ms"] > 0 and v["bytes_per_launch"] > 0 else None} for k, v in prof.items()},
             "elbo": elbos, "gen_seconds": t_gen,
+            "timing_blocks": {"repeats": len(blocks), "steps_per_block": args.steps, "median_s": dt, "min_s": min(blocks),
+                              "max_s": max(blocks), "value_from": "median block"},
         }
         # whole-sweep view: SURVEY 8(d)'s canonical DENSE bytes per iteration (three passes over X,R + ELBO share)
         # against the wall time of a sweep.  The engine makes ONE pass per sweep (sufficient statistics) over report
@@ -202,10 +237,165 @@ def main():
             out["time_to_converge"] = time_to_converge(cfg, net, eng, seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds, eng)
+        eng.close()
+        del net, R
+        torch.cuda.empty_cache()
+        if not args.no_extra and world == 1 and args.config == "c3":
+            t_extra = time.perf_counter()
+            try:
+                out["c5_layer"] = c5_layer_block(local)
+            except Exception as e:   # (a smaller GPU, or memory held by someone else: the headline line must still come out)
+                out["c5_layer"] = {"error": repr(e)}
+            left = args.extra_seconds - (time.perf_counter() - t_extra)
+            try:
+                out["small_fits"] = small_fits_block(local, left) if left > 10 else {"skipped": "time budget"}
+            except Exception as e:
+                out["small_fits"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    eng.close()
+    else:
+        eng.close()
     if dist is not None:
         dist.barrier()   # rank 0 may still be in its (untimed) convergence fit
+        dist.destroy_process_group()
+
+
+def c5_layer_block(device, N=8000, M=1000, K=3, sweeps=10):
+    """BASELINE configs[4], one GPU's share: ONE layer of L=8, N=8000, M=1000, K=3 (64 GB of X generated on the device).
+    Outside the timed region of `value`.  Per kernel class: average launch time (HIP events on the engine's stream),
+    algorithmic bytes, fraction of the 8 TB/s HBM peak; `single_pass_model_frac` restates the whole sweep against the bytes ONE
+    pass over the lists would move (entries + log prior + rho write)."""
+    import torch
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    t0 = time.perf_counter()
+    net = standard_sbm(N=N, M=M, L=1, K=K, C=2, avg_degree=5.0, eta=0.5, seed=0, device=f"cuda:{device}")
+    eng = CaviEngine(net.X, None, K=K, mutuality=True, device=device)
+    del net
+    torch.cuda.empty_cache()
+    sum_x, cov = eng.data_stats()
+    cfg = dict(L=1, N=N, M=M, K=K, mutuality=True)
+    host, pr = draw_state(cfg, 1, sum_x, cov)
+    eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+    eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+    del pr
+    t_setup = time.perf_counter() - t0
+    eng.step(1, want_elbo=True)
+    eng.profile(True)
+    t0 = time.perf_counter()
+    eng.step(sweeps)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    e = eng.step(1, want_elbo=True)   # (outside the timed sweeps: the ELBO variant, for the per-kernel table)
+    prof = eng.profile_read()
+    _, nnz = eng.data_format()
+    eng.close()
+    one_pass = 4.0 * nnz + 2.0 * 8.0 * N * N * K
+    kern = {}
+    for k, v in prof.items():
+        if not v["launches"]:
+            continue
+        ms = v["ms"] / v["launches"]
+        kern[k] = {"avg_ms": ms, "launches": v["launches"], "bytes": v["bytes_per_launch"],
+                   "frac_of_8TBps": (v["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 and v["bytes_per_launch"] else None}
+    return {"workload": f"one layer of BASELINE configs[4]: N={N} M={M} K={K}, mutuality on, all-ones mask, generated on the device",
+            "nnz": nnz, "ms_per_sweep": 1e3 * dt / sweeps, "sweeps_per_s": sweeps / dt, "kernels": kern,
+            "single_pass_bytes": one_pass, "single_pass_model_frac": one_pass / (dt / sweeps) / 1e9 / HBM_PEAK_GBS,
+            "elbo_after_sweeps": e, "setup_seconds": t_setup}
+
+
+def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
+    """BASELINE configs[3] shape (tools/bench_batch.py): Karnataka-like villages (self-reporter mask, M-dim = N, 4 layers fitted
+    separately, K=2, 5 realisations x <= 101 iterations per fit; karnataka.py:170-191) through vimure_amd.batch from ONE
+    process.  Outside the timed region of `value`."""
+    import warnings
+    from vimure_amd.batch import fit_datasets
+    from vimure_amd.synthetic import standard_sbm
+    from vimure_amd.tensor import SparseTensor
+    warnings.simplefilter("ignore")
+    data = {}
+    for v, N in enumerate(sizes):
+        net = standard_sbm(N=N, M=N, L=4, K=2, avg_degree=3.0, eta=0.3, seed=v, flag_self_reporter=True)
+        data[f"vil{v}"] = (SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R))
+    fit_datasets({"w": data["vil0"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=device)   # warm-up
+    t0 = time.perf_counter()
+    df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=8, device=device)
+    dt = time.perf_counter() - t0
+    sweeps = float(df["iters"].sum())   # (iterations of the best realisation only: a lower bound on the sweeps run)
+    return {"workload": f"{len(sizes)} villages N={list(sizes)} x 4 layers x {n_seeds} seeds, 5 realisations x <= 101 iterations each",
+            "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": 8,
+            "mean_fit_seconds": float(df["seconds"].mean()), "sweeps_per_s_lower_bound": sweeps / dt}
+
+
+def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3):
+    """BASELINE configs[4]: ONE fit whose layers live on different GPUs, one layer per rank (vimure_amd.sharded)."""
+    import torch
+    from vimure_amd.sharded import fit_layer_sharded
+    from vimure_amd.synthetic import standard_sbm
+    if world < 2:
+        raise SystemExit("--config c5 shards the LAYERS of one fit over the ranks: --gpus >= 2 (the stated configuration is 8)")
+    net = standard_sbm(N=N, M=M, L=1, K=K, C=2, avg_degree=5.0, eta=0.5, seed=rank, device=dev)
+    n_sweeps = args.warmup + args.steps
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = fit_layer_sharded(net.X, None, [rank], world, K, dist, seed=1, num_realisations=1, max_iter=n_sweeps, device=local)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        its = res["trace"][-1][2] if res["trace"] else n_sweeps
+        print(json.dumps({"metric": f"CAVI sweeps/sec of ONE layer-sharded fit (L={world} N={N} M={M} K={K}, one layer per GPU)",
+                          "value": its / float(tt.item()), "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(tt.item()) / max(1, its), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[4]: L={world} N={N} M={M} K={K}, layer-sharded, whole fit incl. set-up of the "
+                                                 f"initial state; a 3-double RCCL all-reduce per sweep", "iterations": its, "rccl_world": world},
+                          "elbo": res["maxL"], "note": "includes the host draw and upload of the initial state (1.5 GB per layer)"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def bench_c4_batch(args, rank, world, local, dev, dist):
+    """BASELINE configs[3]: (village, layer, seed) fits sharded over the ranks, gathered with one all_gather."""
+    import torch
+    import warnings
+    from vimure_amd.batch import fit_datasets
+    from vimure_amd.synthetic import standard_sbm
+    from vimure_amd.tensor import SparseTensor
+    warnings.simplefilter("ignore")
+    g = np.random.RandomState(0)
+    sizes = g.randint(200, 801, size=args.villages)   # the measured village sizes of the reference's data: N ~ 200-800
+    data = {}
+    for v, N in enumerate(sizes):
+        net = standard_sbm(N=int(N), M=int(N), L=4, K=2, avg_degree=3.0, eta=0.3, seed=v, flag_self_reporter=True)
+        data[f"vil{v:02d}"] = (SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R))
+    fit_datasets({"w": data["vil00"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=local)   # warm-up
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    df = fit_datasets(data, K=2, seeds=range(args.seeds), num_realisations=5, max_iter=101, workers=8, device=local,
+                      dist=dist if world > 1 else None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "Karnataka-shaped fits/sec (village x layer x seed units, 5 realisations x <= 101 iterations each)",
+                          "value": len(df) / dt, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / max(1, len(df)), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[3] shape: {args.villages} villages (N=M in 200..800, self-reporter mask) x 4 "
+                                                 f"layers x {args.seeds} seeds = {len(df)} fits, sharded over {world} rank(s)",
+                                     "rccl_world": world}}), flush=True)
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

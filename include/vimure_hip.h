@@ -58,7 +58,7 @@ enum {
  * Dataset handle.  Replaces the data set-up half of `__check_fit_params`
  * (model.py:134-213).  The dense count tensor is turned into REPORT LISTS on the device -- one 4-byte entry per non-zero
  * count carrying the mirrored count X[l,j,i,m], so X^T (model.py:141-161 `data_T`, `data_T_vals`) is never
- * materialised -- and then freed; tensors that are not sparse enough (or hold counts above 63, or M > 8192) stay as
+ * materialised -- and then freed; tensors that are not sparse enough (or with M > 8192) stay as
  * dense uint8 tiles with R packed to one bit per (l,i,j,m).  vmr_data_format tells which.
  *   X  [L,N,N,M] uint8 counts (values <= 255).
  *   R  [L,N,N,M] uint8 0/1, or NULL = every reporter may report on every tie
@@ -76,11 +76,11 @@ int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutu
  * sptensor built by `read_from_edgelist` (_io.py:132-295) or `preprocess` (utils.py:220-248), and `R.subs` of a sparse
  * reporter mask; `__check_fit_params` derives `data_T_vals` from them with an O(nnz^2) lookup (model.py:148-161).  No dense
  * [L,N,N,M] tensor is built anywhere: the lists are sorted on the device and become the report lists directly.
- *   nx reports: xl, xi, xj, xm (int32 subscripts) and xv (counts, 1..63); no duplicates.
+ *   nx reports: xl, xi, xj, xm (int32 subscripts) and xv (counts, 1..2047); no duplicates.
  *   nr mask entries rl, ri, rj, rm (R = 1 there, 0 elsewhere); nr < 0: every reporter may report on every tie
  *   (model.py:206-211).
  *   data_on_device != 0: all index arrays are device pointers on `device`.
- * Needs M <= 8192; counts above 63 or wider tensors go through vmr_create.
+ * Needs M <= 8192 and (largest count + 1) * M <= 2^20; wider tensors go through vmr_create.
  */
 int vmr_create_coo(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality,
                    int64_t nx, const int32_t* xl, const int32_t* xi, const int32_t* xj, const int32_t* xm, const int32_t* xv,
@@ -146,6 +146,14 @@ int vmr_elbo(vmr_handle h, double* out);
 int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3);
 int vmr_commit_nu(vmr_handle h, double nu_partial_total);
 
+/* The same exchange without a host hop per sweep (RCCL on GPUs): vmr_sweep_local_dev queues the sweep and leaves the three
+ * doubles in the caller's DEVICE buffer out3_dev (asynchronous on the handle's stream); the caller all-reduces that buffer
+ * ON THE HANDLE'S STREAM (vmr_stream returns the hipStream_t; e.g. torch.cuda.ExternalStream) and vmr_commit_nu_dev reads the
+ * total from device memory, again on that stream.  Only ELBO evaluations (every 10th sweep) bring numbers to the host. */
+int vmr_sweep_local_dev(vmr_handle h, int want_elbo, double* out3_dev);
+int vmr_commit_nu_dev(vmr_handle h, const double* nu_partial_total_dev);
+void* vmr_stream(vmr_handle h);
+
 /* One update of a sweep (test hook for step-level parity with model.py:643-656). */
 int vmr_sub_step(vmr_handle h, int which);
 
@@ -158,7 +166,8 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
  * `_update_optimal_parameters` copies into the `*_f` attributes (model.py:925-942), without moving rho (8 L N^2 K bytes)
  * to the host after every realisation; vmr_restore makes the snapshot the current state again, so that
  * vmr_get_state / vmr_get_geometric read the best realisation once, at the end of `fit`.  Asynchronous on the
- * handle's stream. */
+ * handle's stream.  The snapshot does not hold the log prior of its realisation: after vmr_restore the state can be read
+ * (vmr_get_*, vmr_readout, vmr_sample) but the sweeping entry points return VMR_ESTATE until the next vmr_set_state. */
 int vmr_snapshot(vmr_handle h);
 int vmr_restore(vmr_handle h);
 
@@ -169,6 +178,14 @@ int vmr_restore(vmr_handle h);
  *   VMR_READ_THRESHOLD  out uint8 [L,N,N]   rho[...,1] >= threshold
  * out_on_device != 0: `out` is a device pointer.  Synchronises. */
 int vmr_readout(vmr_handle h, int method, double threshold, void* out, int out_on_device);
+
+/* Posterior samples of Y on the device -- `sample_inferred_model` (model.py:1062-1096; also the draw of
+ * `PosteriorSyntheticNetwork`, synthetic.py:964-1177): per tie, n_trials categorical trials from the CURRENT rho and the most
+ * frequent category (first maximum), i.e. Generator.multinomial(n_trials, rho).argmax(-1).  out uint8 [L,N,N].  The uniforms
+ * are Philox4x32-10 with key = seed and counter = (tie index, trial): reproducible for a seed, independent of the data
+ * layout, NOT NumPy's PCG64 stream (the host class keeps that exact mode).  rho (8 L N^2 K bytes) stays on the device.
+ * out_on_device != 0: `out` is a device pointer.  Synchronises. */
+int vmr_sample(vmr_handle h, uint64_t seed, int n_trials, uint8_t* out, int out_on_device);
 
 /* exp(E[log .]) of theta [L,M], lambda [L,K], nu from the current shape/rate parameters
  * (model.py:676-684), plus g_nu_cache = the G_exp_nu the last cache refresh held, i.e. the

@@ -201,3 +201,73 @@ def test_long_steps_two_categories(mask, monkeypatch):
         assert abs(e - e_cpu) <= 1e-9 * abs(e_cpu), (it, e, e_cpu)
     _assert_state(eng.get_state(), c, e, e_cpu)
     eng.close()
+
+
+def test_config5_layer_at_stated_size():
+    """BASELINE configs[4] as stated -- L=8, N=8000, M=1000, K=3, one layer per GPU: ONE GPU's share (a 64 GB layer generated on
+    the device, 1.2 G reports) through a sweep, checked by properties that need no 200-second oracle build:
+      * every tie's rho sums to 1 (model.py:808-811);
+      * rho of 20 000 sampled ties recomputed on the host from the engine's own gamma / phi / nu and those ties' reports -- the
+        rho update is per tie given the parameter tables (model.py:795-811, 889-923);
+      * gamma_rte from the all-ones mask sums of the prior (model.py:704-718);
+      * the mass identity sum_m (gamma_shp - alpha) + (nu partial) = sum(X) at fixed parameters and rho: w1 + w2 = 1 per report
+        (model.py:685-696), i.e. every one of the layer's reports was counted exactly once by the statistics;
+      * the ELBO fused into the sweep equals the stand-alone one (model.py:948-1019).
+    The N=1500 oracle test above stays the bit-level check of this regime."""
+    import scipy.special as sp
+    import torch
+    from vimure_amd import CaviEngine, _lib
+    from vimure_amd.synthetic import standard_sbm
+    L, N, M, K = 1, 8000, 1000, 3
+    EPS = 1e-12
+    net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.5, seed=0, device="cuda:0")
+    eng = CaviEngine(net.X, None, K=K, mutuality=True, device=0)
+    assert eng.data_format()[0] == "sparse"
+    sum_x, cov = eng.data_stats()
+    init = _host_state(L, N, M, K, True, 1, sum_x, cov)
+    g_shp0, g_rte0, p_shp0, p_rte0, nu_shp0, nu_rte0, pr = init
+    eng.set_priors(*PRI)
+    eng.set_state(*init)
+    nu_part, e_main, e_q = eng.sweep_local(want_elbo=True)   # gamma, phi, rho (+ ELBO terms); nu NOT committed
+    st = eng.get_state(rho=True)
+    rho = st["rho"]
+    assert np.isfinite(rho).all()
+    assert np.abs(rho.sum(axis=-1) - 1.0).max() < 1e-12
+    assert st["nu_shp"] == nu_shp0   # (not committed)
+    # gamma_rte = beta + sum_k E[lambda_k]_old sum_t pr_rho_k: the mask is all ones (the pass that sums rho over ties)
+    S0 = pr.reshape(-1, K).sum(axis=0)
+    np.testing.assert_allclose(st["gamma_rte"][0], PRI[1] + float(((p_shp0 / p_rte0)[0] * S0).sum()), rtol=1e-11)
+    # sampled ties
+    g = np.random.RandomState(5)
+    n = 20000
+    ii, jj = g.randint(0, N, n), g.randint(0, N, n)
+    di, dj = torch.as_tensor(ii, device="cuda:0"), torch.as_tensor(jj, device="cuda:0")
+    xs = net.X[0, di, dj].cpu().numpy().astype(np.float64)    # [n, M] the ties' reports
+    ys = net.X[0, dj, di].cpu().numpy().astype(np.float64)    # mirrored counts
+    lth = sp.psi(st["gamma_shp"][0]) - np.log(st["gamma_rte"][0])
+    lla = sp.psi(st["phi_shp"][0]) - np.log(st["phi_rte"][0])
+    Eth, Ela = st["gamma_shp"][0] / st["gamma_rte"][0], st["phi_shp"][0] / st["phi_rte"][0]
+    gnu = float(np.exp(sp.psi(st["nu_shp"]) - np.log(st["nu_rte"])))
+    z2 = gnu * ys                                              # [n, M]
+    a = np.log(pr[0, ii, jj] + EPS) - Eth.sum() * Ela[None, :]
+    for k in range(K):
+        z1 = (np.exp(lth) * np.exp(lla[k]))[None, :]
+        den = z1 + z2
+        den[den == 0.0] = 1.0
+        a[:, k] += (xs * (lth[None, :] + lla[k]) * (z1 / den)).sum(axis=1)
+    ex = np.exp(a)
+    sm = ex.sum(axis=1, keepdims=True)
+    want = np.where(sm > 0, ex / np.where(sm > 0, sm, 1.0), ex)
+    np.testing.assert_allclose(rho[0, ii, jj], want, rtol=1e-9, atol=1e-13)
+    # mass identity at fixed parameters and rho: the gamma sub-step now uses the same theta, lambda, nu and rho as nu_part did
+    eng.sub_step(_lib.STEP_GAMMA)
+    g2 = eng.get_state(rho=False)["gamma_shp"][0]
+    assert abs((g2 - PRI[0]).sum() + nu_part - sum_x) <= 1e-10 * sum_x, ((g2 - PRI[0]).sum(), nu_part, sum_x)
+    # a fused sweep + ELBO at full size, against the stand-alone ELBO pass
+    eng.set_state(*init)
+    e1 = eng.step(2, want_elbo=True)
+    assert np.isfinite(e1)
+    assert abs(eng.elbo() - e1) <= 1e-9 * abs(e1)
+    eng.close()
+    del net
+    torch.cuda.empty_cache()

@@ -89,3 +89,44 @@ def test_several_realisations_keep_the_best_on_the_device():
     np.testing.assert_allclose(m.gamma_shp_f, d["fit_gamma_shp_f"], rtol=1e-6)
     assert m.seed == int(d["fit_final_seed"])
     m.close()
+
+
+def test_device_sampler_distribution_and_reproducibility():
+    """`sample_inferred_model(device=True)` / vmr_sample: a categorical draw per tie from the rho kept on the GPU (reference
+    model.py:1062-1096, synthetic.py:964-1177).  NumPy's PCG64 stream cannot be followed on a GPU, so the device mode is held
+    to the DISTRIBUTION: per-tie frequencies over 3000 samples inside binomial bounds of the reference's golden rho_f, both
+    for single trials and for the reference's "mode of N trials" form; identical output for identical seeds; the exact host
+    mode stays the default."""
+    d, m = _fit("B_random_mask_K3", keep_engine=True)          # K = 3, random mask
+    eng, ref = m._engine, d["fit_rho_f"]
+    L, N, K = m.L, m.N, 3
+    a, b = eng.sample(7), eng.sample(7)
+    assert a.shape == (L, N, N) and a.dtype == np.uint8 and a.max() <= K - 1
+    assert np.array_equal(a, b) and not np.array_equal(a, eng.sample(8))
+    S = 3000
+    freq = np.zeros((L, N, N, K))
+    for s in range(S):
+        y = eng.sample(1000 + s)
+        for k in range(K):
+            freq[..., k] += (y == k)
+    freq /= S
+    sd = np.sqrt(np.maximum(ref * (1.0 - ref), 1e-12) / S)
+    z = np.abs(freq - ref) / (sd + 1.0 / S)
+    assert z.max() < 6.5, z.max()                               # ~1.4e5 cells: 6.5 sigma leaves no room for a wrong table
+    assert (z > 3.0).mean() < 0.01
+    # the reference's sample i of N: argmax of N multinomial trials (ties -> first maximum)
+    Y3 = m.sample_inferred_model(N=3, seed=11, device=True)
+    assert len(Y3) == 3 and all(y.shape == (L, N, N) for y in Y3)
+    assert all(np.array_equal(y, eng.sample(11 + i, n_trials=3)) for i, y in enumerate(Y3))
+    hit = np.mean([eng.sample(500 + s, n_trials=3) == np.argmax(ref, axis=-1) for s in range(200)])
+    one = np.mean([eng.sample(500 + s, n_trials=1) == np.argmax(ref, axis=-1) for s in range(200)])
+    assert hit >= one                                           # the mode of 3 trials sits on argmax rho at least as often
+    assert m._rho_f is None                                     # rho never crossed PCIe
+    # posterior-predictive network with Y drawn on the device
+    from vimure_amd.synthetic import PosteriorSyntheticNetwork
+    net = PosteriorSyntheticNetwork(m, seed_Y=7, device=True)
+    net.build_Y()
+    assert np.array_equal(net.Y.toarray(), a.astype(net.Y.toarray().dtype))
+    m.close()
+    with pytest.raises(ValueError, match="keep_engine"):
+        m.sample_inferred_model(device=True)

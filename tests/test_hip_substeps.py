@@ -17,8 +17,8 @@ def _setup(name):
     import os
     from vimure_amd import CaviEngine
     d = load_case(name)
-    if os.environ.get("VMR_FORMAT") == "sparse" and int(d["X"].max()) > 63:
-        pytest.skip("report lists hold counts up to 63; this case stays on the dense tiles (run by the dense leg)")
+    if os.environ.get("VMR_FORMAT") == "sparse" and int(d["X"].max()) > 2047:
+        pytest.skip("report lists hold counts up to 2047; this case stays on the dense tiles (run by the dense leg)")
     K, mut, und, seed, priors, fitargs, rho_prior = case_config(d)
     L, N, _, M = d["X"].shape
     pr = vo.make_priors(L, M, K, **priors)

@@ -199,3 +199,33 @@ def test_karnataka_tables_match_the_reference_loops():
     assert list(s.columns) == ["running_time", "num_realisations", "max_iter", "initial_seed", "best_seed", "best_elbo", "eta_est",
                                "lambda_k", "model", "village", "layer"] and len(s) == 1 and s["lambda_k"][0] == [0.01, 1.3]
     assert list(t["trace"].columns[-3:]) == ["model", "village", "layer"]
+
+
+def test_layer_draw_skips_the_other_layers_of_the_stream():
+    """A rank of a layer-sharded fit draws only its own layers of pr_rho (reference model.py:470-482: one
+    `rand(L, N, N, K)`): the generator is skipped over the others, and ends where the full draw ends."""
+    from vimure_amd import _hostlib
+    if _hostlib.load() is None:
+        pytest.skip("no C compiler for the host helper")
+    L, N, K = 6, 41, 3
+    cov = (np.random.RandomState(1).rand(L, N, N) < 0.9).astype(np.uint8)
+    ref = np.random.RandomState(11)
+    full = 1.0 + 0.01 * ref.rand(L, N, N, K)
+    full[..., 0] += 0.5
+    full /= full.sum(axis=-1)[..., None]
+    onehot = np.zeros(K)
+    onehot[0] = 1.0
+    full[cov == 0] = onehot
+    after = ref.random_sample(4)
+    for layers in ([0], [2, 5], [1, 2, 3], list(range(L))):
+        g = np.random.RandomState(11)
+        part = _hostlib.draw_pr_rho_layers(g, L, N, K, 0.5, layers, cov[layers])
+        assert np.array_equal(part, full[layers]), layers
+        assert np.array_equal(g.random_sample(4), after), layers
+    g = np.random.RandomState(3)
+    h = np.random.RandomState(3)
+    assert _hostlib.mt_skip(g, 1000)
+    h.random_sample(1000)
+    assert np.array_equal(g.random_sample(5), h.random_sample(5))
+    # K = 8: NumPy sums the 8 terms pairwise, the C pass does not -- the helper steps aside (NumPy statements run)
+    assert _hostlib.draw_pr_rho(np.random.RandomState(0), (1, 5, 5, 8), 0.0, None) is None

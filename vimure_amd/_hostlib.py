@@ -2,6 +2,7 @@
 prior (reference model.py:470-482, 536-556).  Host glue only; when the helper cannot be built the NumPy statements run."""
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -9,13 +10,24 @@ from . import build as _build
 
 _lib = None
 _tried = False
+_load_lock = threading.Lock()
 
 
 def load():
+    """Built and bound once; callers that arrive while another thread is still building wait for it (batch.py creates
+    engines from several threads at once)."""
     global _lib, _tried
     if _lib is not None or _tried:
         return _lib
-    _tried = True
+    with _load_lock:
+        if _lib is not None or _tried:
+            return _lib
+        _lib = _load_locked()
+        _tried = True
+    return _lib
+
+
+def _load_locked():
     try:
         path = _build.build_host()
         lib = C.CDLL(path)
@@ -23,10 +35,9 @@ def load():
         lib.vmr_host_draw_pr_rho.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         lib.vmr_host_mt_skip.restype = None
         lib.vmr_host_mt_skip.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int64]
-        _lib = lib
+        return lib
     except Exception:   # no compiler on this host: the caller falls back to NumPy (same numbers, slower)
-        _lib = None
-    return _lib
+        return None
 
 
 _pool = None
@@ -52,7 +63,7 @@ def draw_pr_rho(prng, shape, bias0, coverage, out=None, threads=None):
     if lib is None:
         return None
     L, N, _, K = shape
-    if K > 64:
+    if K >= 8:   # NumPy's sum(axis=-1) switches to its 8-accumulator pairwise order at 8 terms; the C pass adds left to right
         return None
     st = prng.get_state()
     if st[0] != "MT19937":
@@ -84,7 +95,6 @@ def draw_pr_rho(prng, shape, bias0, coverage, out=None, threads=None):
         # words take 11 ms whoever does them) and publishes each block's state as it reaches it; the other threads draw the
         # blocks as their states arrive.  (Each block skipping from the start on its own cost the last one the whole chain
         # before its first number.)
-        import threading
         nblk = int(min(512, max(nthr, ties * K >> 19)))
         cuts = [ties * i // nblk for i in range(nblk + 1)]
         states, ready, ends = [None] * nblk, [threading.Event() for _ in range(nblk)], [None] * nblk
@@ -108,3 +118,43 @@ def draw_pr_rho(prng, shape, bias0, coverage, out=None, threads=None):
         key, pos = ends[-1]   # the last block ends where the whole draw ends
     prng.set_state(("MT19937", key, pos, st[3], st[4]))
     return out.reshape(shape)
+
+
+def mt_skip(prng, n_doubles):
+    """Advance `prng` (np.random.RandomState) past n_doubles values of `random_sample` without producing them (two 32-bit
+    outputs each; vmr_host_mt_skip).  Returns False when the helper is unavailable (the caller then draws and drops)."""
+    lib = load()
+    if lib is None or n_doubles < 0:
+        return False
+    st = prng.get_state()
+    if st[0] != "MT19937":
+        return False
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int(int(st[2]))
+    lib.vmr_host_mt_skip(key.ctypes.data, C.byref(pos), 2 * int(n_doubles))
+    prng.set_state(("MT19937", key, pos.value, st[3], st[4]))
+    return True
+
+
+def draw_pr_rho_layers(prng, L_total, N, K, bias0, layers, coverage_local):
+    """The rows `layers` (sorted) of the pr_rho that `draw_pr_rho(prng, (L_total, N, N, K), ...)` would return, leaving `prng`
+    where the full draw leaves it: the generator skips the other layers' numbers instead of producing them (a rank of a
+    layer-sharded fit owns 1 of 8 layers of 192 M doubles each).  coverage_local: [len(layers), N, N].  None when the helper is
+    unavailable."""
+    if load() is None or K >= 8:
+        return None
+    out = np.empty((len(layers), N, N, K), np.float64)
+    per = N * N * K
+    cursor = 0
+    for q, l in enumerate(layers):
+        if l < cursor:
+            raise ValueError("layers must be sorted and distinct")
+        if not mt_skip(prng, (l - cursor) * per):
+            return None
+        cov = None if coverage_local is None else coverage_local[q:q + 1]
+        if draw_pr_rho(prng, (1, N, N, K), bias0, cov, out=out[q:q + 1]) is None:
+            return None
+        cursor = l + 1
+    if not mt_skip(prng, (L_total - cursor) * per):
+        return None
+    return out

@@ -37,6 +37,10 @@ SIGNATURES = {
     "vmr_sub_step": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_sweep_local": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_commit_nu": (C.c_int, [C.c_void_p, C.c_double]),
+    "vmr_sweep_local_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "vmr_commit_nu_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vmr_stream": (C.c_void_p, [C.c_void_p]),
+    "vmr_sample": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int]),
     "vmr_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "vmr_get_geometric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vmr_sync": (C.c_int, [C.c_void_p]),

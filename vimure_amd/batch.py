@@ -64,7 +64,7 @@ def _fit_unit(Xl, Rl, K, seeds, mutuality, device, name, keep, fit_kwargs):
 
 def _as_data(X, R):
     """Coordinate containers stay as they are (when the report lists can hold them); everything else becomes dense uint8."""
-    if is_sparse_like(X) and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 63)):
+    if is_sparse_like(X) and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 2047)):
         return X, R
     Xd = to_dense_u8(X, "X")
     Rd = None if R is None else (to_dense_u8(R, "R") != 0).astype(np.uint8)

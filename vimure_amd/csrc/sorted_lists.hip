@@ -1,0 +1,157 @@
+// sorted_lists.hip -- builds the sorted report lists (layout: sweep_sl.h) from tie-major entries, once per dataset, and
+// the permutation kernels of the boundary functions.  Replaces the data set-up of `__check_fit_params` (model.py:136-171)
+// together with vmr_create / vmr_create_coo in vimure_hip.hip.
+#include "sweep_sl.h"
+
+// keys = per-tie report counts, values = tie index (one layer)
+__global__ __launch_bounds__(256) void k_sl_keys(const unsigned* __restrict__ cnt, unsigned* __restrict__ keys, unsigned* __restrict__ vals, size_t T) {
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (size_t)gridDim.x * 256) { keys[t] = cnt[t]; vals[t] = (unsigned)t; }
+}
+// per step: slots = 64 * (count of the step's first = most reported tie); the sorted order padded to whole steps
+__global__ __launch_bounds__(256) void k_sl_steps(const unsigned* __restrict__ keys_sorted, const unsigned* __restrict__ vals_sorted,
+                                                  unsigned* __restrict__ sz, unsigned* __restrict__ perm, size_t T, size_t NS) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < NS * 64; q += (size_t)gridDim.x * 256) {
+    perm[q] = q < T ? vals_sorted[q] : 0xffffffffu;
+    if ((q & 63) == 0) sz[q >> 6] = 64u * keys_sorted[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sz[NS] = 0u;
+}
+// one wave per step: lane <-> position; round r of the step = the r-th entry of every tie (0 where it has fewer)
+__global__ __launch_bounds__(256) void k_sl_place(const unsigned* __restrict__ perm, const unsigned* __restrict__ rpl /*scanned, by tie*/,
+                                                  const unsigned* __restrict__ rsl, const unsigned* __restrict__ Ein,
+                                                  unsigned* __restrict__ Eout, unsigned* __restrict__ syl, size_t T, size_t NS, int Mp) {
+  const int lane = threadIdx.x & 63;
+  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
+    const unsigned t = perm[s * 64 + lane];
+    const bool ok = t != 0xffffffffu;
+    const unsigned r0 = ok ? rpl[t] : 0u, n = ok ? rpl[t + 1] - r0 : 0u;
+    const unsigned ea = rsl[s], R = (rsl[s + 1] - ea) >> 6;
+    unsigned ymx = 0;
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned e = n > r ? Ein[(size_t)r0 + r] : 0u;
+      Eout[(size_t)ea + r * 64 + lane] = e;
+      ymx = max(ymx, SL_YM(e) / (unsigned)Mp);
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) ymx = max(ymx, (unsigned)__shfl_xor((int)ymx, o2, 64));
+    if (lane == 0) syl[s] = ymx;
+  }
+}
+
+template <class V>
+__global__ __launch_bounds__(256) void k_sl_gather(const unsigned* __restrict__ perm, const V* __restrict__ in, V* __restrict__ out,
+                                                   size_t T, size_t NS, int L) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)L * T; q += (size_t)gridDim.x * 256) {
+    const size_t l = q / T, pos = q - l * T;
+    out[q] = in[l * T + perm[l * NS * 64 + pos]];
+  }
+}
+// rows of K doubles: out[pos] = in[perm[pos]] (to_pos) or out[perm[pos]] = in[pos]; K threads per row
+__global__ __launch_bounds__(256) void k_sl_rows(const unsigned* __restrict__ perm, const double* __restrict__ in, double* __restrict__ out,
+                                                 size_t T, size_t NS, int L, int K, int to_pos) {
+  const size_t n = (size_t)L * T * K;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const size_t row = q / K, k = q - row * K, l = row / T, pos = row - l * T;
+    const size_t t = perm[l * NS * 64 + pos];
+    if (to_pos) out[q] = in[(l * T + t) * K + k]; else out[(l * T + t) * K + k] = in[q];
+  }
+}
+
+int sl_permute_u8(vmr_ctx* h, const uint8_t* in, uint8_t* out) {
+  const Geo& g = h->g;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
+  hipLaunchKernelGGL(k_sl_gather<uint8_t>, dim3((unsigned)std::min<size_t>(8192, (g.L * T + 255) / 256)), dim3(256), 0, h->stream, h->perm, in, out, T, NS, g.L);
+  CK(hipGetLastError());
+  return VMR_OK;
+}
+int sl_permute_u32(vmr_ctx* h, const unsigned* in, unsigned* out) {
+  const Geo& g = h->g;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
+  hipLaunchKernelGGL(k_sl_gather<unsigned>, dim3((unsigned)std::min<size_t>(8192, (g.L * T + 255) / 256)), dim3(256), 0, h->stream, h->perm, in, out, T, NS, g.L);
+  CK(hipGetLastError());
+  return VMR_OK;
+}
+int sl_permute_rows(vmr_ctx* h, const double* in, double* out, bool to_pos) {
+  const Geo& g = h->g;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64, n = (size_t)g.L * T * g.K;
+  hipLaunchKernelGGL(k_sl_rows, dim3((unsigned)std::min<size_t>(16384, (n + 255) / 256)), dim3(256), 0, h->stream, h->perm, in, out, T, NS, g.L, g.K, to_pos ? 1 : 0);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+
+int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, const SlFill* fill) {
+  Geo& g = h->g;
+  const int L = g.L;
+  const size_t T = (size_t)g.N * g.N, n = T + 1, NS = (T + 63) / 64;
+  unsigned *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *bsum = nullptr, *etmp = nullptr;
+  void* tmp = nullptr;
+  auto cleanup = [&]() { void* p[] = {keys, keys2, vals, vals2, bsum, etmp, tmp}; for (void* q : p) if (q) (void)hipFree(q); };
+#define CKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); cleanup(); return VMR_EHIP; } } while (0)
+  if (T >= 0x7fffffffull) return fail(nullptr, VMR_EINVAL, "more than 2^31 ties in one layer");
+  CKS(hipMalloc(&keys, T * 4)); CKS(hipMalloc(&keys2, T * 4)); CKS(hipMalloc(&vals, T * 4)); CKS(hipMalloc(&vals2, T * 4));
+  CKS(hipMalloc(&bsum, (std::max(n, NS + 1) + 2047) / 2048 * 4));
+  CKS(hipMalloc(&h->rs, (size_t)L * (NS + 1) * 4));
+  CKS(hipMalloc(&h->perm, (size_t)L * NS * 64 * 4));
+  CKS(hipMalloc(&h->sy, (size_t)L * NS * 4));
+  size_t tb = 0;
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) <= (unsigned long long)g.M) ++bits;   // a tie holds at most M reports
+  CKS(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, vals2, (int)T, 0, bits, h->stream));
+  CKS(hipMalloc(&tmp, tb ? tb : 8));
+  const unsigned tgrid = (unsigned)std::min<size_t>(8192, (T + 255) / 256), sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
+  for (int l = 0; l < L; ++l) {
+    unsigned* rpl = rp + (size_t)l * n;
+    unsigned* rsl = h->rs + (size_t)l * (NS + 1);
+    hipLaunchKernelGGL(k_sl_keys, dim3(tgrid), dim3(256), 0, h->stream, rpl, keys, vals, T);
+    CKS(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, vals2, (int)T, 0, bits, h->stream));   // (stable: equal counts keep tie order)
+    hipLaunchKernelGGL(k_sl_steps, dim3((unsigned)std::min<size_t>(8192, (NS * 64 + 255) / 256)), dim3(256), 0, h->stream, keys2, vals2, rsl,
+                       h->perm + (size_t)l * NS * 64, T, NS);
+    CKS(hipGetLastError());
+    int rc;
+    if ((rc = scan_u32(h, rsl, bsum, NS + 1)) || (rc = scan_u32(h, rpl, bsum, n))) { cleanup(); return rc; }
+  }
+  CKS(hipStreamSynchronize(h->stream));
+  std::vector<unsigned> slots(L);
+  for (int l = 0; l < L; ++l) CKS(hipMemcpy(&slots[l], h->rs + (size_t)l * (NS + 1) + NS, 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> eb(L);
+  h->n_slots = 0;
+  for (int l = 0; l < L; ++l) {
+    eb[l] = h->n_slots; h->n_slots += slots[l];
+    if ((double)slots[l] < (double)nl[l]) { cleanup(); return fail(nullptr, VMR_EINVAL, "more than 2^32 report slots in one layer"); }
+  }
+  CKS(hipMalloc(&h->ebase, (size_t)L * 8));
+  CKS(hipMemcpy(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice));
+  CKS(hipMalloc(&h->E, ((size_t)h->n_slots + SL_SLACK) * 4));
+  CKS(hipMemsetAsync(h->E + h->n_slots, 0, (size_t)SL_SLACK * 4, h->stream));
+  if (!etmp_all) {
+    unsigned long long nlmax = 0;
+    for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
+    CKS(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
+  }
+  unsigned long long off = 0;
+  for (int l = 0; l < L; ++l) {
+    unsigned* src = etmp_all ? etmp_all + off : etmp;
+    if (!etmp_all) (*fill)(l, rp + (size_t)l * n, etmp);
+    hipLaunchKernelGGL(k_sl_place, dim3(sgrid), dim3(256), 0, h->stream, h->perm + (size_t)l * NS * 64, rp + (size_t)l * n,
+                       h->rs + (size_t)l * (NS + 1), src, h->E + eb[l], h->sy + (size_t)l * NS, T, NS, g.Mp);
+    off += nl[l];
+  }
+  CKS(hipGetLastError());
+  CKS(hipStreamSynchronize(h->stream));
+#undef CKS
+  cleanup();
+  return VMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the per-K sweep launchers (sweep_sl.hip, one object per K; a development build links only some of them)
+// ------------------------------------------------------------------------------------------
+#define SL_DECL(K_) __attribute__((weak)) int vmr_sl_launch_k##K_(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a);
+SL_DECL(2) SL_DECL(3) SL_DECL(4) SL_DECL(5) SL_DECL(6) SL_DECL(7) SL_DECL(8)
+sl_launch_fn vmr_sl_launcher(int K) {
+  switch (K) {
+    case 2: return vmr_sl_launch_k2; case 3: return vmr_sl_launch_k3; case 4: return vmr_sl_launch_k4; case 5: return vmr_sl_launch_k5;
+    case 6: return vmr_sl_launch_k6; case 7: return vmr_sl_launch_k7; case 8: return vmr_sl_launch_k8;
+    default: return nullptr;
+  }
+}

@@ -1,0 +1,68 @@
+// sweep_sl.h -- the sorted report lists (the default data format of a sparse X) and the sweep kernel over them.
+//
+// Ties of a layer are SORTED by their number of reports (descending, stable) and taken in steps of 64 consecutive sorted
+// positions -- one wave, one tie per lane.  After the sort the ties of a step hold (almost) the same number of reports, so a
+// step is R_s full rounds of 64 slots and nothing else:
+//     E[ebase[l] + rs[l][s] + r * 64 + lane]   the r-th report of the tie at position s * 64 + lane (0 = none)
+//     entry   bits 0..19  y * Mp + m  (mirror count y = X[l,j,i,m], 0 when mutuality is off; reporter m): the row of the
+//                         per-(y, m) tables F and H        bit 20  R[l,i,j,m]        bits 21..31  the count x (<= 2047)
+//     rs[l][s] (u32, NS + 1 per layer)   first slot of step s;  R_s = (rs[s+1] - rs[s]) / 64, non-increasing in s
+//     perm[l][pos] (u32)                 the tie (i * N + j) at sorted position pos (0xffffffff beyond the last tie)
+//     sy[l][s] (u32)                     the highest mirror count y among the step's reports (which table levels it needs)
+// Padding only appears in the ~max-count steps per layer where the count changes.  Every per-tie array the sweeps touch is
+// stored BY POSITION (rho, log prior, mask-row class, the ELBO's mirror sums Qt), so all of a wave's accesses are contiguous;
+// the boundary functions (vmr_set_state, vmr_get_state, vmr_readout, vmr_sample) translate through perm.
+#ifndef VMR_SWEEP_SL_H
+#define VMR_SWEEP_SL_H
+
+#include "vmr_internal.h"
+#include <functional>
+
+#define SL_YM(e) ((e) & 0xfffffu)
+#define SL_INR(e) (((e) >> 20) & 1u)
+#define SL_X(e) ((e) >> 21)
+#define SL_XMAX 2047u          // largest count an entry holds
+#define SL_YM_ROWS (1u << 20)  // (max count + 1) * Mp must not exceed this
+#define SL_PF 8                // rounds of a step that are prefetched one step ahead (registers)
+#define SL_SLACK (64 * 64)     // entry slots past the last one that prefetches may read (never use)
+
+struct SlArgs {
+  const unsigned* E; const unsigned* rs; const unsigned long long* ebase; const unsigned* perm;
+  const unsigned* sy;    // [L][NS] highest mirror-count level among the reports of a step
+  const uint8_t* cls;    // [L][T] mask-row class by position: 0 empty, 1 all ones, 2 partial (null: every row is all ones)
+  const unsigned* Qt;    // [L][T] by position: sum_m R[t,m] X[mirror(t),m]
+  const uint64_t* Rb; const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask rows, by TIE
+  double* rho; const double* logpr;   // [L][T][K] by position
+  const double* par; double* slotR; const double* lutg; double* Hg; double* slotF; double* slotA; const double* Fg;
+  int Gl;        // workgroups per layer
+  int do_hist;   // 1: accumulate the statistics H; 2: count mode (vmr_create): every tie is category 1, slot 1 gets sum x
+  int yt, hc;    // levels (mirror counts 0..) of F / of H held in LDS
+  int sum_a;     // also sum the (new) rho over the listed reporters of the partial mask rows into slotA
+};
+
+struct SlShape { int tpb, yt, hc; size_t smem; };
+
+// LDS bytes of one workgroup of the sweep kernel
+static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {
+  const size_t lb = (size_t)g.Mp * g.K * 8;
+  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) +
+         (size_t)g.W * 8 + 128 + (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
+}
+
+// mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2)
+typedef int (*sl_launch_fn)(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a);
+sl_launch_fn vmr_sl_launcher(int K);   // null when K was not compiled in
+
+// sorted_lists.hip
+// Builds perm, rs, E (and ebase, n_slots) from tie-major entries.  rp [L][T+1]: per-tie report counts (overwritten by their
+// exclusive scan); nl[l]: reports of layer l; etmp_all: every layer's entries tie-major (layer l at offset sum nl[<l]) or null,
+// then fill(l, rp_l scanned, etmp) writes layer l's.
+typedef std::function<void(int l, const unsigned* rpl, unsigned* etmp)> SlFill;
+int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, const SlFill* fill);
+// out[l][pos] = in[l][perm[l][pos]] for the per-tie arrays the sweeps read by position
+int sl_permute_u8(vmr_ctx* h, const uint8_t* in, uint8_t* out);
+int sl_permute_u32(vmr_ctx* h, const unsigned* in, unsigned* out);
+// [L][T][K] doubles between tie order and position order (to_pos: out[pos] = in[perm[pos]]; else out[perm[pos]] = in[pos])
+int sl_permute_rows(vmr_ctx* h, const double* in, double* out, bool to_pos);
+
+#endif

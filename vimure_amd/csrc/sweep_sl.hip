@@ -1,0 +1,573 @@
+// sweep_sl.hip -- ONE pass over the sorted report lists per CAVI sweep: the rho update (model.py:763-818, 889-923), the
+// sufficient statistics H of the new rho (what gamma / phi / nu are finished from: model.py:698-761, 820-887) and the ELBO's
+// data terms (model.py:948-995).  Compiled once per number of categories (-DVMR_K=2..8), one object each.
+//
+// A wave takes steps of 64 consecutive sorted positions, one tie per lane (layout: sweep_sl.h).  Ties are sorted by their
+// number of reports, so every lane of a step walks the same number of rounds R, and R never grows from one step of a wave to
+// its next.  A step is
+//   prefetch   the next step's per-tie values (log prior or rho, mask class) and its rounds are requested at the top of the
+//              step, after ONE wait for this step's own (requested a step ago); the slot range and the highest table level of
+//              the step after next ride in three lanes of a vector register (a scalar load would be waited for with
+//              lgkmcnt(0): LDS queue drained)
+//   walk 1     U_k = sum_r x_r F[y_r, m_r, k]: the table reads back to back, then the FMAs
+//   update     rho = exp(log prior + U - T E[lambda]) normalised where the sum is positive: raw exp, as model.py:807
+//   walk 2     H[y_r, m_r, k] += x_r rho_k for k >= 1 (LDS float atomics; H_0 is rebuilt from the constant sum of x); the ELBO
+//              variant takes its logarithms here
+// Consecutive steps of a wave with the same R run in a loop compiled for that R (R = 0..SL_PF): straight-line code with no
+// per-report branch, no scatter and no workgroup barrier, and a back edge at which the compiler knows every request's age.  The populous levels (mirror counts) of F and H live in
+// LDS, shared by all waves of a workgroup; a step whose reports reach a level beyond them (known per step from the list
+// build) takes the general code -- global reads and atomics -- and steps of more than SL_PF rounds stream the further ones
+// through a register ring.
+#include "sweep_sl.h"
+
+#ifndef VMR_K
+#error "compile with -DVMR_K=<number of categories>"
+#endif
+#ifndef SL_WPE
+#define SL_WPE 4   // waves per SIMD the kernel is compiled for
+#endif
+#define SL_TPB_MAX 1024
+#define SL_RG 8    // loads in flight over the further rounds of a long step
+
+template <int K>
+struct StepIn {          // what is prefetched for one step
+  double v[K];           // log prior (UPDATE or ELBO)
+  double w[K];           // current rho (not UPDATE)
+  unsigned cls, qt, tie;
+  unsigned e[SL_PF];
+};
+
+template <int R> struct RC { static constexpr int value = R; };
+#define SL_INL __attribute__((always_inline))
+// table rows read back to back: as many as keep the batch within ~32 registers
+template <int K> struct Batch { static constexpr int value = K <= 2 ? 8 : (K <= 4 ? 4 : 2); };
+
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+__global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int Mp = g.Mp;
+  const unsigned ytm = UPDATE ? (unsigned)a.yt * (unsigned)Mp : 0u;     // rows (y, m) of F held in LDS
+  const unsigned hcm = a.do_hist ? (unsigned)a.hc * (unsigned)Mp : 0u;  // rows of H held in LDS
+  size_t off = 0;
+  double* F = reinterpret_cast<double*>(smem + off); off += (size_t)ytm * K * 8;            // [yt][Mp][K]
+  const int nHc = (int)hcm * (K - 1);
+  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                // [K-1][hc][Mp]
+  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)Mp * 8 : 0;
+  double* As = reinterpret_cast<double*>(smem + off); off += a.sum_a ? (size_t)Mp * K * 8 : 0;   // [Mp][K]
+  double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
+  double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
+  double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;
+  double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
+  const ParOff o = par_off(g.L, g.Mp, g.K);
+  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const size_t T = (size_t)g.N * g.N;
+  const long long NS = (long long)((T + 63) / 64);
+  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  const double* Fl = a.Fg + (size_t)l * g.Y * Mp * K;
+  for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
+  for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
+  if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
+  if (UPDATE || ELBO) sp_math_tables(xt, lt, tid, nthr);
+  if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
+  const double* lut = a.lutg + (size_t)l * g.W * 256;
+  for (int w = tid; w < g.W; w += nthr) {
+    double v = 0.0;
+    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
+    wsum[w] = v;
+  }
+  double Ela[K], Gla[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; }
+  const double eps = g.eps;
+  const float rcp_mp = 1.0f / (float)Mp;
+  double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
+  double accF[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) accF[k] = 0.0;
+  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
+  const unsigned* rsl = a.rs + (size_t)l * (NS + 1);
+  const unsigned* syl = a.sy + (size_t)l * NS;
+  const unsigned* El = a.E + a.ebase[l];
+  const unsigned* pl = a.perm + (size_t)l * NS * 64;
+  const uint8_t* cl = ALLFULL ? nullptr : a.cls + (size_t)l * T;
+  const unsigned* Ql = a.Qt ? a.Qt + (size_t)l * T : nullptr;
+  const uint64_t* Rl = a.Rb ? a.Rb + (size_t)l * T * g.W : nullptr;
+  double* rl = a.rho + (size_t)l * T * K;
+  const double* lpl = a.logpr + (size_t)l * T * K;
+  const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
+  const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
+  const double* Eth = a.par + o.E_th + (size_t)l * Mp;
+  // a step is "far" when one of its reports lies in a level beyond the LDS copies this launch holds
+  const unsigned lim_y = UPDATE ? (a.do_hist ? (unsigned)min(a.yt, a.hc) : (unsigned)a.yt) : (a.do_hist ? (unsigned)a.hc : 0xffffffffu);
+
+  // steps of this wave: s = gw, gw + GW, ...  (waves interleave: neighbouring waves read neighbouring memory, and every wave
+  // sees the whole range of R)
+  const long long GW = (long long)a.Gl * nw, gw = (long long)gb * nw + wv;
+  long long s = gw;
+  unsigned ea = 0;    // first slot of the current step
+  int R = 0;          // its rounds
+  unsigned ymax = 0;  // its highest mirror-count level
+  unsigned rgv = 0;   // lanes 0..2: rs[s2], rs[s2 + 1], sy[s2] of the NEXT step (loaded one step earlier)
+  StepIn<K> P;        // the prefetched step
+
+  auto fetch_range = [&](long long st) SL_INL { rgv = lane < 2 ? rsl[st + lane] : (lane == 2 ? syl[st] : 0u); };
+  // loads of one step's per-tie values ...
+  auto fetch_tie = [&](StepIn<K>& d, long long st) SL_INL {
+    const size_t pos = (size_t)st * 64 + lane;
+    const bool ok = pos < T;
+    d.qt = 0u; d.tie = 0u;
+    if (ALLFULL) d.cls = ok ? 1u : 0u;
+    else {
+      d.cls = ok ? (unsigned)cl[pos] : 0u;
+      d.tie = ok ? pl[pos] : 0u;   // (partial mask rows are found by tie)
+    }
+    if (ELBO && Ql) d.qt = ok ? Ql[pos] : 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { d.v[k] = 0.0; d.w[k] = 0.0; }
+    if ((UPDATE || ELBO) && ok) load_k<K>(lpl + pos * K, d.v);
+    if (!UPDATE && ok && a.do_hist != 2) load_k<K>(rl + pos * K, d.w);
+  };
+  // ... and of its first CNT rounds (rounds it does not have read later steps' slots, unused; in bounds: SL_SLACK)
+  auto fetch_ent = [&](StepIn<K>& d, unsigned base, auto cntc) SL_INL {
+    constexpr int CNT = decltype(cntc)::value;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) d.e[j] = El[(size_t)base + (unsigned)lane + (unsigned)j * 64];
+  };
+
+  if (s < NS) {   // prologue: this wave's first step
+    ea = rsl[s];
+    R = (int)((rsl[s + 1] - ea) >> 6);
+    ymax = syl[s];
+    fetch_range(s + GW < NS ? s + GW : s);
+    fetch_tie(P, s);
+    fetch_ent(P, ea, RC<SL_PF>{});
+  }
+  __syncthreads();   // tables
+  double Tfull = 0.0;
+  for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
+
+  // ---- pieces of a step -------------------------------------------------------------------------------------------
+  // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749)
+  auto add_lists = [&](unsigned t, bool on, const double (&rr)[K]) SL_INL {
+    unsigned q0 = 0, q1 = 0;
+    if (on) { q0 = rql[t]; q1 = rql[t + 1]; }
+    for (unsigned i = 0;; ++i) {
+      const bool v = q0 + i < q1;
+      const unsigned long long vm = __ballot(v);
+      if (vm == 0ull) break;
+      const int m = v ? (int)Rml[q0 + i] : -1;
+      const int m0 = __builtin_amdgcn_readlane(m, __builtin_ctzll(vm));
+      if (__all(!v || m == m0)) {   // one reporter for the whole wave (ties (i, j..j+63) of a self-reporter mask): one add
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const double sm_ = wave_sum(v ? rr[k] : 0.0);
+          if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
+        }
+      } else if (v) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
+      }
+    }
+  };
+  // T = sum_m R E[theta_m] of this lane's tie (model.py:766-792)
+  auto mask_sum = [&](unsigned cls, unsigned tie) SL_INL -> double {
+    if (ALLFULL) return Tfull;
+    double Tt = 0.0;
+    if (cls == 1u) Tt = Tfull;
+    else if (cls == 2u && rql) {
+      const unsigned q0 = rql[tie], q1 = rql[tie + 1];
+      for (unsigned q = q0; q < q1; ++q) Tt += Eth[Rml[q]];
+    } else if (cls == 2u) {
+      const uint64_t* rwt = Rl + (size_t)tie * g.W;
+      for (int w = 0; w < g.W; ++w) {
+        uint64_t bits = rwt[w];
+        if (bits == ~0ull) { Tt += wsum[w]; continue; }
+        for (int n = 0; bits != 0; ++n, bits >>= 4) Tt += lut[((w * 16 + n) << 4) + (unsigned)(bits & 15u)];
+      }
+    }
+    return Tt;
+  };
+  // the K factors of a (y, m) row that may lie beyond the LDS levels
+  auto f_row_any = [&](unsigned ym, double (&f)[K]) SL_INL {
+    const bool far = ym >= ytm;
+    const unsigned il = (far ? 0u : ym) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) f[k] = F[il + k];
+    if (__any(far)) {
+      if (far) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) f[k] = Fl[(size_t)ym * K + k];
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the value must not cross the join as a pending load
+        asm volatile("" ::: "memory");
+      }
+    }
+  };
+  // one report into H, any level, with the deficit x (1 - sum rho) of an irregular tie in slot 0 (global)
+  auto h_add_any = [&](unsigned ym, const double (&xr)[K], double xd, bool on) SL_INL {
+    if (on) {
+      if (ym < hcm) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], xr[k]);
+      } else {
+        double* d = Hl + (size_t)ym * K;
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&d[k], xr[k]);
+        asm volatile("" ::: "memory");
+      }
+      if (xd != 0.0) atomicAdd(&Hl[(size_t)ym * K], xd);
+    }
+  };
+  // sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps, eps alone outside R  (model.py:967-995)
+  auto elbo_inner = [&](unsigned ent, const double (&er)[K]) SL_INL -> double {
+    const unsigned ym = SL_YM(ent);
+    unsigned y = (unsigned)((float)ym * rcp_mp);
+    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
+    double inner = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+    return (SL_INR(ent) ? inner : 0.0) + eps;
+  };
+  // U += x F[row] over NP entries whose rows are all in LDS: the table reads in batches, back to back
+  auto walk1_near = [&](const unsigned* e, auto npc, double (&U)[K]) SL_INL {
+    constexpr int NP = decltype(npc)::value, BT = Batch<K>::value;
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += BT) {
+      double f[BT][K];
+#pragma unroll
+      for (int u = 0; u < BT; ++u) {
+        if (j0 + u < NP) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) f[u][k] = F[SL_YM(e[j0 + u]) * K + k];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BT; ++u) {
+        if (j0 + u < NP) {
+          const double dx = (double)SL_X(e[j0 + u]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) U[k] = fma(dx, f[u][k], U[k]);
+        }
+      }
+    }
+  };
+  // H += x rho (+ the ELBO's log terms) over NP entries whose rows are all in LDS; an empty slot adds 0
+  auto walk2_near = [&](const unsigned* e, auto npc, const double (&r)[K], const double (&er)[K]) SL_INL {
+    constexpr int NP = decltype(npc)::value;
+    double in_[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const unsigned ym = SL_YM(e[j]);
+      const double dx = (double)SL_X(e[j]);
+      if (a.do_hist) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
+      }
+      if (ELBO) in_[j] = elbo_inner(e[j], er);
+    }
+    if (ELBO) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) e_log += (double)SL_X(e[j]) * log_tab(in_[j], lt);
+    }
+  };
+  // the deficits x (1 - sum_k rho_k) of ties whose rho does not sum to 1 go to slot 0 of H (global; rare)
+  auto deficit = [&](unsigned ent, double dfc) SL_INL {
+    const unsigned x = SL_X(ent);
+    if (x != 0u && dfc != 0.0) atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);
+  };
+  auto near1 = [&](unsigned ent, double (&U)[K]) SL_INL {
+    const double dx = (double)SL_X(ent);
+#pragma unroll
+    for (int k = 0; k < K; ++k) U[k] = fma(dx, F[SL_YM(ent) * K + k], U[k]);
+  };
+  // one report, any level: the general walks
+  auto gen1 = [&](unsigned ent, double (&U)[K]) SL_INL {
+    double f[K];
+    f_row_any(SL_YM(ent), f);
+    const double dx = (double)SL_X(ent);
+#pragma unroll
+    for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
+  };
+  auto gen2 = [&](unsigned ent, const double (&r)[K], const double (&er)[K], double dfc) SL_INL {
+    const unsigned x = SL_X(ent);
+    const double dx = (double)x;
+    double xr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) xr[k] = dx * r[k];
+    if (a.do_hist) h_add_any(SL_YM(ent), xr, dx * dfc, x != 0u);
+    if (ELBO) e_log += dx * log_tab(elbo_inner(ent, er), lt);
+  };
+
+  // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
+  auto body = [&](auto rct) SL_INL {
+    constexpr int RCT = decltype(rct)::value;
+    constexpr int NP = RCT < 0 ? SL_PF : RCT;   // rounds held in registers
+    const size_t pos = (size_t)s * 64 + lane;
+    const bool act = pos < T;
+    const unsigned ea_c = ea;
+    const int Rr = RCT < 0 ? R : RCT;
+    const bool far = RCT < 0 && ymax >= lim_y;   // (wave-uniform; the straight-line bodies only see near steps)
+    // Everything this step needs was requested a whole step ago: wait for it HERE, before the next step's requests go out.
+    // (Left to itself the compiler waits at the first use, after the new requests -- and where it cannot tell how many
+    // requests are younger than the ones it needs it drains them all: memory latency in every step.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    const StepIn<K> cur = P;
+    // the next step: its range was loaded a step ago; its per-tie values and rounds now.  It has at most as many rounds as
+    // this one (sorted order), so NP loads cover them; surplus loads read later steps' slots, unused.  After the wave's last
+    // step the same loads are issued once more, of this step's own (valid) addresses: no branch around a load.
+    const long long s2 = s + GW;
+    const bool more = s2 < NS;
+    const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
+    const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
+    const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
+    fetch_range(s2 + GW < NS ? s2 + GW : s);
+    fetch_tie(P, more ? s2 : s);
+    fetch_ent(P, ea2, RC<NP>{});
+    const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
+    // rounds beyond the prefetched ones: a ring of SL_RG loads in flight (clamped to the step's last round: no branch around
+    // a load)
+    unsigned rg[SL_RG];
+    auto ring_addr = [&](int j) SL_INL { return (size_t)ea_c + (unsigned)lane + (unsigned)(j < Rr ? j : Rr - 1) * 64; };
+    auto ring_fill = [&]() SL_INL {
+#pragma unroll
+      for (int i = 0; i < SL_RG; ++i) rg[i] = El[ring_addr(SL_PF + i)];
+    };
+    auto ring_walk = [&](auto&& use) SL_INL {   // use(entry) for rounds SL_PF .. Rr-1, in order
+      for (int j0 = SL_PF; j0 < Rr; j0 += SL_RG) {
+#pragma unroll
+        for (int i = 0; i < SL_RG; ++i) {
+          const unsigned c = rg[i];
+          rg[i] = El[ring_addr(j0 + i + SL_RG)];
+          if (j0 + i < Rr) use(c);   // (wave-uniform)
+        }
+      }
+    };
+    double r[K], er[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { r[k] = cur.w[k]; er[k] = 0.0; }
+    if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
+#pragma unroll
+      for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
+    }
+    double Tt = 0.0;
+    if (UPDATE || ELBO) Tt = mask_sum(cls, tie);
+    double dfc = 0.0;
+    bool irr = false;
+
+    if (UPDATE) {
+      // ---- walk 1
+      double U[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) U[k] = 0.0;
+      if (RCT >= 0) walk1_near(cur.e, RC<NP>{}, U);
+      else if (far) {
+#pragma unroll
+        for (int j = 0; j < SL_PF; ++j) if (j < Rr) gen1(cur.e[j], U);
+        if (Rr > SL_PF) { ring_fill(); ring_walk([&](unsigned c) SL_INL { gen1(c, U); }); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SL_PF; ++j) if (j < Rr) near1(cur.e[j], U);   // (a general step of few rounds: not the hot path)
+        if (Rr > SL_PF) {
+          ring_fill();
+          constexpr int GB = Batch<K>::value < SL_RG ? Batch<K>::value : SL_RG;
+          for (int j0 = SL_PF; j0 < Rr; j0 += SL_RG) {
+#pragma unroll
+            for (int gi = 0; gi < SL_RG; gi += GB) {
+              unsigned c[GB];
+#pragma unroll
+              for (int u = 0; u < GB; ++u) {
+                c[u] = (j0 + gi + u < Rr) ? rg[gi + u] : 0u;   // (wave-uniform select; an empty entry adds 0 * F[0])
+                rg[gi + u] = El[ring_addr(j0 + gi + u + SL_RG)];
+              }
+              if (j0 + gi < Rr) walk1_near(c, RC<GB>{}, U);
+            }
+          }
+        }
+      }
+      // ---- per-tie update from the finished sums
+      double aa[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) aa[k] = (cur.v[k] + U[k]) - Tt * Ela[k];
+      bool done = false;
+      if (K == 2) {
+        // two categories: rho_0 = 1 / (1 + e^(a1-a0)) -- one exp, one reciprocal -- wherever the reference's raw exponentials
+        // neither overflow nor underflow (then equal to exp(a_k) / sum up to rounding); other ties below
+        const double d = aa[1] - aa[0];
+        const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
+        if (__all(safe)) {
+          const double e = exp_tab(d, xt);
+          r[0] = 1.0 / (1.0 + e);
+          r[1] = e * r[0];
+          done = true;
+        }
+      }
+      if (!done) {
+        double sum = 0.0;
+        bool tame = true;   // every a_k of the wave's ties where exp neither overflows nor underflows (else: the library's)
+#pragma unroll
+        for (int k = 0; k < K; ++k) tame = tame && fabs(aa[k]) < 700.0;
+        tame = __all(tame);
+        if (tame) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] = exp_tab(aa[k], xt);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] = exp(aa[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum += r[k];   // no max-subtraction, as model.py:807
+        if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
+#pragma unroll
+          for (int k = 0; k < K; ++k) r[k] /= sum;
+        }
+        if (a.do_hist) {   // does every tie's rho sum to 1?  (the K = 2 formula does by construction)
+          double sm = 0.0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) sm += r[k];
+          dfc = 1.0 - sm;
+          if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;
+          irr = __any(dfc != 0.0);
+        }
+      }
+      if (act) {
+        store_k<K>(rl + pos * K, r);
+        if (ALLFULL || cls == 1u) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) accF[k] += r[k];
+        }
+      }
+      if (!ALLFULL && a.sum_a) add_lists(tie, act && cls == 2u, r);
+    } else if (a.do_hist) {
+      // the current rho: does it sum to 1 (a user-supplied prior may not)?
+      double sm = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sm += r[k];
+      dfc = 1.0 - sm;
+      if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;
+      irr = __any(dfc != 0.0);
+      if (!ELBO && a.do_hist == 1 && act && (ALLFULL || cls == 1u)) {   // all-ones mask rows are summed here too
+#pragma unroll
+        for (int k = 0; k < K; ++k) accF[k] += r[k];
+      }
+      if (!ALLFULL && !ELBO && a.sum_a) add_lists(tie, act && cls == 2u, r);
+    }
+    if (ELBO) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) er[k] = exp_tab(r[k], xt);   // exp(rho), model.py:971
+    }
+    // ---- walk 2: H of the (new) rho, the ELBO's log terms
+    if (a.do_hist || ELBO) {
+      if (RCT >= 0) {
+        walk2_near(cur.e, RC<NP>{}, r, er);
+        if (irr) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) deficit(cur.e[j], dfc);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SL_PF; ++j) if (j < Rr) gen2(cur.e[j], r, er, dfc);
+        if (Rr > SL_PF) { ring_fill(); ring_walk([&](unsigned c) SL_INL { gen2(c, r, er, dfc); }); }   // (the same rounds again: from the L2)
+      }
+    }
+    if (ELBO && act) {
+      double sr = 0.0, se = 0.0, en = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        sr += r[k]; se += r[k] * Ela[k];
+        en += r[k] * cur.v[k] - r[k] * log_tab(r[k] + eps, lt);   // model.py:1306-1313
+      }
+      e_lin += en - se * Tt;
+      if (Ql) e_q += sr * (double)qt;
+    }
+    // advance
+    s = s2; ea = ea2; R = R2; ymax = ym2;
+  };
+  // consecutive steps of this wave with the same number of rounds run in one straight-line loop
+  auto run = [&](auto rct) SL_INL {
+    constexpr int RCT = decltype(rct)::value;
+    do { body(rct); } while (s < NS && R == RCT && ymax < lim_y);
+  };
+  while (s < NS) {
+    if (R > SL_PF || ymax >= lim_y) { body(RC<-1>{}); continue; }
+    switch (R) {
+      case 0: run(RC<0>{}); break;
+      case 1: run(RC<1>{}); break;
+      case 2: run(RC<2>{}); break;
+      case 3: run(RC<3>{}); break;
+      case 4: run(RC<4>{}); break;
+      case 5: run(RC<5>{}); break;
+      case 6: run(RC<6>{}); break;
+      case 7: run(RC<7>{}); break;
+      default: run(RC<8>{}); break;
+    }
+  }
+
+  __syncthreads();
+  if (a.do_hist) {   // flush the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
+    for (int q = tid; q < nHc; q += nthr) {
+      const double v = Hc[q];
+      if (v != 0.0) {
+        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
+        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
+      }
+    }
+  }
+  if (a.sum_a) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K])
+    double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
+    for (int q = tid; q < g.M * K; q += nthr) {
+      const double v = As[q];
+      if (v != 0.0) atomicAdd(&out[q], v);
+    }
+  }
+  if (UPDATE || (!ELBO && a.do_hist == 1)) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double v = block_sum_n(accF[k], red);
+      if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
+    }
+  }
+  if (ELBO) {
+    double v1 = block_sum_n(e_lin, red);
+    double v2 = block_sum_n(e_log, red);
+    double v3 = block_sum_n(e_q, red);
+    if (tid == 0) {
+      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launcher of this object's K
+// ------------------------------------------------------------------------------------------
+template <bool UPDATE, bool ELBO, bool ALLFULL>
+static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
+  constexpr int K = VMR_K;
+  const Geo& g = h->g;
+  const long long NS = ((long long)g.N * g.N + 63) / 64, nw = sh.tpb / 64;
+  int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
+  return VMR_OK;
+}
+
+#define SL_CAT2(a, b) a##b
+#define SL_CAT(a, b) SL_CAT2(a, b)
+int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
+  if (a.cls == nullptr) {   // every mask row is all ones
+    switch (mode) {
+      case 0: return sl_launch_one<true, false, true>(h, sh, a);
+      case 1: return sl_launch_one<true, true, true>(h, sh, a);
+      case 2: return sl_launch_one<false, true, true>(h, sh, a);
+      default: return sl_launch_one<false, false, true>(h, sh, a);
+    }
+  }
+  switch (mode) {
+    case 0: return sl_launch_one<true, false, false>(h, sh, a);
+    case 1: return sl_launch_one<true, true, false>(h, sh, a);
+    case 2: return sl_launch_one<false, true, false>(h, sh, a);
+    default: return sl_launch_one<false, false, false>(h, sh, a);
+  }
+}

@@ -15,216 +15,12 @@
 //   k_gamma_mask   A[l,m,k] = sum_ij R rho: mask words become the EXEC mask of K v_add_f64 (lane <-> reporter).
 //   k_fin_*        one workgroup per layer: gamma, phi, nu from H and A, the Gamma expectations
 //                  (digamma/log/exp), ELBO assembly -- no host round trip inside a sweep.
-#include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <math.h>
-#include <stdlib.h>
-#include <string>
-#include <vector>
-#include <utility>
-#include <algorithm>
-#include <chrono>
-#include <type_traits>
+#include "vmr_internal.h"
+#include "sweep_sl.h"
 
-#include "vimure_hip.h"
+thread_local std::string g_create_err;
 
-#define VMR_VERSION "vimure_hip 0.1 (gfx950)"
-#define TPB 256
-#ifndef VMR_LB_COUNTS
-#define VMR_LB_COUNTS 4   // resident workgroups per CU the gamma/phi sweeps are compiled for
-#endif
-#ifndef VMR_LB_RHO
-#define VMR_LB_RHO 3
-#endif
-#ifndef VMR_NR_STEPS
-#define VMR_NR_STEPS 1   // v_rcp_f64 is good to 4.6e-8; one step gives 2e-15, two are exact (tools/rcp_accuracy.hip)
-#endif
-#define KMAX 8
 
-// ------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------
-struct Geo {
-  int L, N, M, K, mut;
-  int Mp;       // row bytes of X on device (M rounded up to 16)
-  int nchunk;   // Mp / 16
-  int stride;   // LDS row stride in bytes (odd multiple of 16)
-  int W;        // 64-bit words per R row
-  int b, lb;    // tile edge (ties), log2
-  int nb;       // tiles per side
-  int nt;       // tie slots per tile pair = 2 b^2
-  int S, lS;    // lanes per tie
-  long long P;  // tile pairs per layer
-  int Gl;       // workgroups per layer for tile-pair kernels
-  int Gm;       // workgroups per layer for the mask kernel
-  int Y;        // mirror-count levels of the statistics H: max count + 1 (1 when mutuality is off)
-  int hc;       // how many of them are accumulated in LDS (dense tiles: 0..HC_MAX); the rest goes to global atomics
-  int yt;       // report lists: levels of the factor table F the rho pass keeps in LDS; the rest is read from global
-  int fuse_full; // rows of R that are all ones are summed by the rho pass itself (A gets sum_t rho_k for them)
-  int ml;        // report lists with mask lists: the rho / statistics pass sums rho over the listed reporters too (A[Mp][K] in LDS)
-  int two_pass; // wide reporter dimension: the LDS levels do not fit beside the rho pass' tables, so H is rebuilt by
-                // k_hist after the rho pass (two passes over X per sweep instead of one)
-  int pf;       // 16-B chunks of a tile pair each thread stages (prefetch depth)
-  int heavy;    // a lane's share of a row with more non-zeros than this is processed by the whole wave
-  int dbg;      // timing experiments only (env VMR_DEBUG; results are wrong): dense path 1 = skip per-report math, 2 = skip
-                // the scan; report lists 8 = no H flush, 16 = no walk 1, 32 = no walk 2, 64 = no exp in the tie update
-  double eps;
-};
-
-#define NSLOT 8   // accumulation slots per layer for cross-workgroup sums (global f64 atomics)
-
-struct vmr_ctx {
-  Geo g;
-  int device;
-  hipStream_t stream;
-  hipStream_t stream2 = nullptr;     // the mask half of the gamma update runs beside the counts half
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  std::string err;
-  // data
-  uint8_t* X = nullptr;        // [L][N*N][Mp]
-  uint64_t* Rb = nullptr;      // [L][N*N][W]
-  uint8_t* cov = nullptr;      // [L][N*N]
-  uint8_t* rcls = nullptr;     // [L][N*N] class of the mask row: 0 empty, 1 all ones, 2 partial
-  // report lists (sparse format, see k_rho_sp); X is freed once they exist
-  int sparse = 0;
-  unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
-  unsigned* rs = nullptr;      // [L][N*N/64+1] first entry of every 64-tie step, relative to ebase[l]
-  double* Fg = nullptr;        // [L][Y][Mp][K] per-report factors of the rho update (k_build_f / k_fin_gamma)
-  bool ftab_valid = false;     // Fg matches the current parameters
-  double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
-  int sp_tpb = 256;            // threads per workgroup of k_rho_sp
-  unsigned* Qt = nullptr;      // [L][N*N] sum_m R[t,m] X[mirror(t),m]
-  unsigned long long* ebase = nullptr;   // device [L]
-  unsigned long long nnz = 0;  // non-zero counts in X
-  unsigned long long n_slots = 0;   // entry slots of the report lists: nnz + the padding of the full rounds
-  int all_full = 0;            // every mask row is all ones
-  // mask lists (partial rows with few reporters), see k_mask_lists
-  unsigned* rq = nullptr;              // [L][N*N+1]
-  unsigned short* Rm = nullptr;
-  unsigned long long* rbase = nullptr; // device [L]
-  unsigned long long n_rm = 0;         // listed reporters in all
-  unsigned long long* sumx = nullptr;
-  // state
-  double *rho = nullptr, *logpr = nullptr;
-  double* par = nullptr;       // parameter block, see P_* offsets
-  // steady-state sweeps as hipGraphs (vmr_step; env VMR_GRAPH=1).  Measured on the Karnataka-shaped batch (48 fits, 8 host
-  // threads): 22.3 fits/s with graphs against 22.9 without -- the dependent 10 us kernels of a sweep, not the launch calls,
-  // set a small fit's pace -- and a capture is invalidated when another host thread creates or destroys a handle meanwhile
-  // (hipMalloc / hipFree during capture), so the eager path is the default.
-  std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (sweeps in the graph, executable)
-  bool use_graphs = false;
-  double *rho_snap = nullptr, *par_snap = nullptr;   // vmr_snapshot: the best realisation so far (model.py:925-942)
-  bool have_snap = false;
-  size_t par_doubles = 0;
-  // partials
-  double *slotA = nullptr, *slotR = nullptr;   // NSLOT accumulation slots
-  double* Hg = nullptr;        // sufficient statistics H[L][Y][Mp][K]
-  bool h_valid = false;        // H matches the current rho
-  double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
-  bool f_valid = false;        // slotF matches the current rho
-  bool long_steps = false;     // report lists with >= 8 reports per tie on average: the LONG variants of k_rho_sp
-  bool a_valid = false;        // slotA holds the mask-list sums of the current rho (summed by the last rho / statistics pass)
-  bool a_zero = true;          // slotA is known to be all zero
-  bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
-  bool h_zero = false;         // k_fin_gamma consumed H and slotF: both are all zero, ready for the rho pass
-  bool fin_attr = false, ml_attr = false;
-  unsigned long long* npartial = nullptr;   // rows of R that are neither empty nor all ones
-  unsigned long long n_partial = 0;
-  unsigned* xmax = nullptr;
-  double* elbo_dev = nullptr;  // [0] elbo
-  double* lutg = nullptr;      // wide masks (W > 4): the nibble LUT of E[theta] lives in global memory [L][W*256]
-  bool have_priors = false, have_state = false;
-  bool serial = false;
-  int ncu = 256;
-  std::vector<std::pair<const void*, int>> occ;   // kernel -> resident workgroups per CU   // a rho sub-step left an unconsumed nu partial in slotR
-  // profiling
-  bool prof = false;
-  struct Ev { int cls; hipEvent_t a, b; };
-  std::vector<Ev> evs;
-  double prof_ms[VMR_KERNEL_COUNT];
-  int64_t prof_n[VMR_KERNEL_COUNT];
-};
-
-static std::string g_create_err;
-
-// parameter block layout (doubles); LM = L*Mp, LK = L*K
-struct ParOff {
-  size_t a_th, b_th, g_shp, g_rte, E_th, G_th, l_th;   // each L*Mp
-  size_t a_la, b_la, p_shp, p_rte, p_rte_pend, E_la, G_la, l_la;  // each L*K
-  size_t sc;   // scalars: see SC_*
-  size_t total;
-};
-enum { SC_A_ETA = 0, SC_B_ETA, SC_NU_SHP, SC_NU_RTE, SC_G_NU, SC_G_NU_STALE, SC_E_NU, SC_COUNT = 8 };
-
-__host__ __device__ static inline ParOff par_off(int L, int Mp, int K) {
-  ParOff o;
-  size_t LM = (size_t)L * Mp, LK = (size_t)L * K, p = 0;
-  o.a_th = p; p += LM; o.b_th = p; p += LM; o.g_shp = p; p += LM; o.g_rte = p; p += LM;
-  o.E_th = p; p += LM; o.G_th = p; p += LM; o.l_th = p; p += LM;
-  o.a_la = p; p += LK; o.b_la = p; p += LK; o.p_shp = p; p += LK; o.p_rte = p; p += LK;
-  o.p_rte_pend = p; p += LK; o.E_la = p; p += LK; o.G_la = p; p += LK; o.l_la = p; p += LK;
-  o.sc = p; p += SC_COUNT;
-  o.total = p;
-  return o;
-}
-
-#define HIPCHK(h, call)                                                              \
-  do {                                                                               \
-    hipError_t e_ = (call);                                                          \
-    if (e_ != hipSuccess) {                                                          \
-      char buf_[512];                                                                \
-      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      if (h) (h)->err = buf_; else g_create_err = buf_;                              \
-      (void)hipGetLastError(); /* do not leave the error sticky for the next call */ \
-      return VMR_EHIP;                                                               \
-    }                                                                                \
-  } while (0)
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double digamma_pos(double x) {
-  // psi(x), x > 0: upward recurrence to x >= 10, then the asymptotic series
-  // (same construction as cephes/scipy.special.psi, which the reference calls at model.py:676).
-  double r = 0.0;
-  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-  double f = 1.0 / (x * x);
-  double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 +
-             f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
-  return r + log(x) - 0.5 / x + t;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// sum over the S (power of two, group-aligned) lanes that share a tie; every lane gets the sum
-__device__ __forceinline__ double group_sum(double v, int S) {
-  for (int o = S >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ unsigned group_sum_u(unsigned v, int S) {
-  for (int o = S >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// block-wide sum (TPB threads); result valid in thread 0. `red` = >= 4 doubles of LDS.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x == 0) {
-    for (int w = 0; w < TPB / 64; ++w) r += red[w];
-  }
-  return r;
-}
 
 // Non-zero-byte flags of a 16-byte chunk, 16 bits spread over a dword: bit 8*b + i (+4 when hi) is set
 // iff byte b of dword i is non-zero.  Two chunks (hi = 0/1) share one dword, four one 64-bit word.
@@ -244,13 +40,6 @@ __device__ __forceinline__ void flag_pos(int bit, int& chunk, int& byte) {
   const int lo = bit & 31;                       // position inside the dword of a chunk pair
   chunk = ((bit >> 5) << 1) | ((lo >> 2) & 1);   // dword half, then the +4 flag
   byte = ((lo & 3) << 2) | (lo >> 3);            // dword i = lo & 3, byte b = lo >> 3  ->  4*i + b
-}
-
-// weight of the theta*lambda part of a report (model.py:685-693): z1 / (z1 + z2), 0-safe
-__device__ __forceinline__ double w1_of(double z1, double z2) {
-  double den = z1 + z2;
-  den = (den == 0.0) ? 1.0 : den;
-  return z1 / den;
 }
 
 // decode pair index p -> (I,J), I <= J, row-major over the upper triangle of an nb x nb grid
@@ -351,14 +140,6 @@ struct MaskStream {
   }
 };
 
-// 1/d: v_rcp_f64 (4.6e-8) + VMR_NR_STEPS Newton steps (one: 2e-15, two: exact); the IEEE divide costs ~2x
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-#pragma unroll
-  for (int i = 0; i < VMR_NR_STEPS; ++i) r = fma(fma(-d, r, 1.0), r, r);
-  return r;
-}
-
 // Weights of the cache refresh (model.py:685-693) without a divide per report:
 //   w1 = z1/(z1 + z2) = 1/(1 + c y),  c[m][k] = G_nu / (G_theta[m] G_lambda[k])  (LDS table, built per launch)
 //   w2 = z2/(z1 + z2) = c y w1.
@@ -416,15 +197,6 @@ __device__ __forceinline__ void weights_cb(double (&w)[K], double cb, const doub
     const double r = fast_rcp(1.0 + c[k] * dy);
     w[k] = (y == 0) ? ((c[k] < (double)INFINITY) ? 1.0 : 0.0) : r;
   }
-}
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
-  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
-  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), lane));
 }
 
 
@@ -642,6 +414,18 @@ __global__ void k_init_rho(const double* __restrict__ pr, double* __restrict__ r
   }
 }
 
+// the same for a handle whose rho / log prior live in sorted position order (sweep_sl.h): pr is in tie order
+__global__ void k_init_rho_pos(const double* __restrict__ pr, double* __restrict__ rho, double* __restrict__ logpr,
+                               const unsigned* __restrict__ perm, size_t T, size_t NS, int L, int K, double eps) {
+  const size_t n = (size_t)L * T * K;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = q / K, k = q - row * K, l = row / T, pos = row - l * T;
+    const double v = pr[(l * T + perm[l * NS * 64 + pos]) * K + k];
+    rho[q] = v;
+    logpr[q] = log(v + eps);
+  }
+}
+
 // nibble LUT of E[theta] for wide masks: lut[l][n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3
 __global__ void k_build_lut(const double* __restrict__ par, double* __restrict__ lutg, Geo g) {
   const ParOff o = par_off(g.L, g.Mp, g.K);
@@ -698,7 +482,7 @@ __global__ void k_derive_all(double* par, Geo g) {
 template <int K, int NC>
 __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__ Rb, const double* __restrict__ rho,
                                                     const uint8_t* __restrict__ rcls, double* __restrict__ slotA,
-                                                    int skip_full, Geo g) {
+                                                    int skip_full, const unsigned* __restrict__ perm /* rho by sorted position, or null */, Geo g) {
   __shared__ double sacc[NC * 64 * K];
   const int l = blockIdx.x / g.Gm, gb = blockIdx.x - l * g.Gm;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -709,6 +493,7 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
   const uint64_t* Rl = Rb + (size_t)l * T * g.W;
   const double* rl = rho + (size_t)l * T * K;
   const uint8_t* cl = rcls + (size_t)l * T;
+  const unsigned* pl = perm ? perm + (size_t)l * ((T + 63) / 64) * 64 : nullptr;
   const int Wp = g.W * 64;
   for (int cg = 0; cg < g.W; cg += NC) {
     const int nc = min(NC, g.W - cg);   // == NC except in the last group of a wide mask
@@ -725,11 +510,12 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
     auto fetch = [&](long long tb) {
       long long t = tb + lane;
       bool ok = t < t1;
-      long long tc = ok ? t : t1 - 1;
+      const long long pc = ok ? t : t1 - 1;              // position (= tie when rho is in tie order)
+      const long long tc = pl ? (long long)pl[pc] : pc;   // the tie whose mask row this is
 #pragma unroll
       for (int c = 0; c < NC; ++c) wq[c] = (ok && c < nc) ? Rl[tc * g.W + cg + c] : 0ull;
 #pragma unroll
-      for (int k = 0; k < K; ++k) rq[k] = ok ? rl[tc * K + k] : 0.0;
+      for (int k = 0; k < K; ++k) rq[k] = ok ? rl[pc * K + k] : 0.0;
       cq = ok ? (unsigned)cl[tc] : 0u;
     };
     if (t0 < t1) fetch(t0);
@@ -801,14 +587,6 @@ __global__ __launch_bounds__(TPB) void k_gamma_mask(const uint64_t* __restrict__
 // ([L][Y][Mp][K] doubles, Y = max count + 1); mirror counts 0..HC-1 are accumulated in LDS, the rest with global
 // f64 atomics.  k_hist builds H from the current rho (start of a fit, sub-step tests).
 // ------------------------------------------------------------------------------------------
-#ifndef NH
-#define NH 8
-#endif
-// NH copies of H in global memory (workgroup gb adds into copy gb % NH): spreads the atomics
-#ifndef HC_MAX
-#define HC_MAX 3
-#endif
-// HC_MAX: mirror-count levels cached in LDS when they fit (93 % of the reports at BASELINE config 3); Geo.hc
 
 struct HistArgs {
   const uint8_t* X; const double* rho; double* Hg;
@@ -1346,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_sp_round(const unsigned* __restrict__ r
 template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
                                                  const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
-                                                 unsigned* __restrict__ Qtl, Geo g) {
+                                                 unsigned* __restrict__ Qtl, int sl, Geo g) {
   const int gl = threadIdx.x & 15;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
@@ -1391,7 +1169,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
             y = (ys[u] >> sh) & 0xffu;
             if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
           }
-          El[w++] = (y * (unsigned)g.Mp + (unsigned)m) | (inr << 19) | own | (x << 26);
+          El[w++] = sl ? ((y * (unsigned)g.Mp + (unsigned)m) | (inr << 20) | (x << 21))   // sorted lists (sweep_sl.h)
+                       : ((y * (unsigned)g.Mp + (unsigned)m) | (inr << 19) | own | (x << 26));
         }
       }
       pos += tot;
@@ -1446,7 +1225,8 @@ __global__ __launch_bounds__(256) void k_rm_fill(const uint64_t* __restrict__ Rl
 template <int K>
 __global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__ rq, const unsigned short* __restrict__ Rm,
                                                     const unsigned long long* __restrict__ rbase, const uint8_t* __restrict__ rcls,
-                                                    const double* __restrict__ rho, double* __restrict__ slotA, int Gl, Geo g) {
+                                                    const double* __restrict__ rho, double* __restrict__ slotA, int Gl,
+                                                    const unsigned* __restrict__ perm /* rho by sorted position, or null */, Geo g) {
   extern __shared__ double As[];   // [Mp][K]
   const int l = blockIdx.x / Gl, gb = blockIdx.x - l * Gl;
   const size_t T = (size_t)g.N * g.N;
@@ -1457,12 +1237,14 @@ __global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__
   for (int q = threadIdx.x; q < g.Mp * K; q += TPB) As[q] = 0.0;
   __syncthreads();
   const size_t t0 = (size_t)gb * T / Gl, t1 = (size_t)(gb + 1) * T / Gl;
-  for (size_t t = t0 + threadIdx.x; t < t1; t += TPB) {
+  const unsigned* pl = perm ? perm + (size_t)l * ((T + 63) / 64) * 64 : nullptr;
+  for (size_t p = t0 + threadIdx.x; p < t1; p += TPB) {
+    const size_t t = pl ? (size_t)pl[p] : p;
     if (cl[t] != 2) continue;
     const unsigned q0 = rql[t], q1 = rql[t + 1];
     double r[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) r[k] = rl[t * K + k];
+    for (int k = 0; k < K; ++k) r[k] = rl[p * K + k];
     for (unsigned q = q0; q < q1; ++q) {
       const int m = Rml[q];
 #pragma unroll
@@ -1490,13 +1272,6 @@ struct SpArgs {
   int sum_a;          // (what k_mask_lists does in a pass of its own), into this workgroup's slot of slotA
 };
 
-// Per-report factor of the rho update, a function of (reporter m, mirror count y, category k) only:
-//   F[l][y][m][k] = (E[log theta_lm] + E[log lambda_lk]) * w1_k(m, y),   w1 = z1 / (z1 + z2), den == 0 -> 1   (model.py:685-693, 911-921)
-// so a report contributes x * F to its tie's U_k: one table read and K multiplies instead of a reciprocal per report.
-// Built once per sweep for all levels (a few KB..MB, L2-resident); the rho pass keeps the populous low levels in LDS.
-__device__ __forceinline__ double f_entry(int mut, double lth, double gth, double lla, double gla, double gnu, int y) {
-  return (lth + lla) * (mut ? w1_of(gth * gla, gnu * (double)y) : 1.0);   // mutuality off: data_z1 = x (model.py:680)
-}
 __global__ __launch_bounds__(256) void k_build_f(const double* __restrict__ par, double* __restrict__ Fg, Geo g) {
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x, K = g.K;
@@ -1510,115 +1285,6 @@ __global__ __launch_bounds__(256) void k_build_f(const double* __restrict__ par,
   }
 }
 
-// Orders a wave's LDS traffic across lanes.  The LDS executes one wave's operations in issue order (a ds_read issued
-// after another lane's ds_add to the same address sees it), so all that is needed is that the COMPILER keeps them in
-// program order.  A __builtin_amdgcn_fence here -- even at wavefront scope -- also emits s_waitcnt vmcnt(0), which
-// drains the next step's prefetched global loads at every call and serialises memory latency with the walks.
-__device__ __forceinline__ void wave_sync() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// block-wide sum for any block size (<= 1024 threads); result valid in thread 0.  `red` = 16 doubles of LDS.
-__device__ __forceinline__ double block_sum_n(double v, double* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x == 0) {
-    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) r += red[w];
-  }
-  return r;
-}
-
-// log(x) for positive normal x (what the ELBO terms feed it: x >= eps), < 1 ulp: the classic reduction x = 2^k m,
-// m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-14 even
-// minimax R of FreeBSD msun's e_log.c (coefficients Lg1..Lg7 are that algorithm's published constants).  About 40 VALU
-// instructions against ~100 of the library's log(), which also serves zero, subnormal, negative and infinite arguments;
-// NaN propagates.  One evaluation per report on ELBO sweeps.
-__device__ __forceinline__ double log_pos(double x) {
-  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-               Lg7 = 1.479819860511658591e-01;
-  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-  int k = __builtin_amdgcn_frexp_exp(x);
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m + m : m;
-  k = lo ? k - 1 : k;
-  const double f = m - 1.0, dk = (double)k;
-  const double s = f / (2.0 + f);
-  const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-  const double R = t2 + t1, hfsq = 0.5 * f * f;
-  return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
-}
-
-// Table-driven exp / log for the rho pass (tables in LDS, filled by sp_math_tables): less than half the instructions of the
-// polynomial-only versions, and a shorter dependent chain per tie.
-//   exp_tab(x), |x| < 700:  n = rint(x 64/ln2), r = x - n ln2/64 (|r| <= 0.0055), exp(x) = 2^(n>>6) T[n&63] (1 + r + .. + r^5/120);
-//                            truncation r^6/720 < 4e-17, measured against the library over [-700, 700]: <= 1 ulp
-//   log_tab(x), x > 0 normal: x = 2^k m, m in [0.5, 1), c = midpoint of m's 1/256-wide cell, r = m/c - 1 (|r| <= 2^-8, 1/c tabulated),
-//                            log x = k ln2 + log c + (r - r^2/2 + .. - r^6/6); truncation 2^-56/7: ABSOLUTE error ~2e-16 (what sums of
-//                            ELBO terms need; near x = 1 the relative error is large, unlike log_pos)
-#ifndef SP_TABLE_MATH
-#define SP_TABLE_MATH 1
-#endif
-#define SP_MATH_DOUBLES (64 + 256)
-__device__ __forceinline__ void sp_math_tables(double* xt /*64*/, double* lt /*128 x (1/c, log c)*/, int tid, int nthr) {
-  for (int j = tid; j < 64; j += nthr) xt[j] = exp2((double)j * (1.0 / 64.0));
-  for (int i = tid; i < 128; i += nthr) {
-    const double c = 0.5 + ((double)i + 0.5) * (1.0 / 256.0);
-    lt[2 * i] = 1.0 / c;
-    lt[2 * i + 1] = log(c);
-  }
-}
-__device__ __forceinline__ double exp_tab(double x, const double* xt) {
-  const double nf = __builtin_rint(x * 92.33248261689366);            // 64 / ln 2
-  double r = fma(-nf, 0x1.62e42fee00000p-7, x);                        // ln2/64, upper 32 bits: nf * hi is exact
-  r = fma(-nf, 2.9815858269852933e-12, r);
-  const int n = (int)nf;
-  const double t = xt[n & 63];
-  const double q = r * fma(r, fma(r, fma(r, fma(r, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
-  return __builtin_amdgcn_ldexp(fma(t, q, t), n >> 6);
-}
-__device__ __forceinline__ double log_tab(double x, const double* lt) {
-  const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-  const int k = __builtin_amdgcn_frexp_exp(x);
-  const int i = (__double2hiint(m) >> 13) & 127;
-  const double2 cl = *reinterpret_cast<const double2*>(lt + 2 * i);
-  const double r = fma(m, cl.x, -1.0);
-  const double p = r * fma(r, fma(r, fma(r, fma(r, fma(r, -1.0 / 6.0, 0.2), -0.25), 1.0 / 3.0), -0.5), 1.0);
-  return fma((double)k, 0.6931471805599453, cl.y + p);
-}
-
-// K consecutive doubles of a [.][K] array: 16-byte accesses when K is even (the arrays are 256-byte aligned)
-template <int K>
-__device__ __forceinline__ void load_k(const double* __restrict__ p, double (&v)[K]) {
-  if (K % 2 == 0) {
-#pragma unroll
-    for (int k = 0; k < K; k += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(p + k);
-      v[k] = t.x; v[k + 1 < K ? k + 1 : k] = t.y;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = p[k];
-  }
-}
-template <int K>
-__device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v)[K]) {
-  if (K % 2 == 0) {
-#pragma unroll
-    for (int k = 0; k < K; k += 2) *reinterpret_cast<double2*>(p + k) = make_double2(v[k], v[k + 1 < K ? k + 1 : k]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) p[k] = v[k];
-  }
-}
 
 // rho update (UPDATE), ELBO data terms (ELBO) and the statistics H (a.do_hist) from the report lists.
 // A WAVE takes 64 consecutive ties per step, one per lane for the per-tie work (log prior, mask sum T, exp /
@@ -2579,9 +2245,10 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const 
 }
 
 // commit a nu_shp that was summed over several handles (layer-sharded fits)
-__global__ void k_commit_nu(double* par, double nu_partial_total, Geo g) {
+__global__ void k_commit_nu(double* par, double nu_partial_total, const double* total_dev, Geo g) {
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
+  if (total_dev) nu_partial_total = total_dev[0];   // (summed over the owners on the device: no host hop)
   if (threadIdx.x == 0 && blockIdx.x == 0 && g.mut) {
     sc[SC_G_NU_STALE] = sc[SC_G_NU];
     sc[SC_NU_SHP] = sc[SC_A_ETA] + nu_partial_total;
@@ -2592,9 +2259,11 @@ __global__ void k_commit_nu(double* par, double nu_partial_total, Geo g) {
 
 // posterior read-out per tie (model.py:1099-1188, utils.py:200-217): argmax_k rho, sum_k k rho_k, rho_1 >= threshold
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ rho, void* __restrict__ out, size_t ties, int K,
-                                                 int method, double threshold) {
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ties; t += (size_t)gridDim.x * blockDim.x) {
-    const double* r = rho + t * K;
+                                                 int method, double threshold, const unsigned* __restrict__ perm, size_t T, size_t NS) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < ties; q += (size_t)gridDim.x * blockDim.x) {
+    const double* r = rho + q * K;
+    size_t t = q;
+    if (perm) { const size_t l = q / T, pos = q - l * T; t = l * T + perm[l * NS * 64 + pos]; }   // rho by sorted position, answers by tie
     if (method == VMR_READ_RHO_MAX) {
       int best = 0;
       double bv = r[0];
@@ -2610,13 +2279,58 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ rho,
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Posterior samples of Y on the device: `sample_inferred_model` (model.py:1062-1096) draws, per tie, n_trials categorical
+// trials from rho and keeps the most frequent category (first maximum): Generator.multinomial(n, rho).argmax(-1).  Here the
+// uniforms come from Philox4x32-10 with key = seed and counter = (tie index in [L,N,N] order, trial pair), so a draw depends on
+// (seed, tie, trial) only -- reproducible, and the same for every data layout -- not on NumPy's PCG64 stream, which a GPU cannot
+// follow (the host class keeps that exact mode; this one is checked by distribution).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void k_sample(const double* __restrict__ rho, uint8_t* __restrict__ out, size_t ties, int K, int n_trials,
+                                                unsigned long long seed, const unsigned* __restrict__ perm, size_t T, size_t NS) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < ties; q += (size_t)gridDim.x * blockDim.x) {
+    const double* r = rho + q * K;
+    size_t t = q;
+    if (perm) { const size_t l = q / T, pos = q - l * T; t = l * T + perm[l * NS * 64 + pos]; }
+    unsigned cnt[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) cnt[k] = 0u;
+    for (int n = 0; n < n_trials; n += 2) {
+      unsigned c[4] = {(unsigned)t, (unsigned)((unsigned long long)t >> 32), (unsigned)(n >> 1), 0u};
+      philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (n + i < n_trials) {
+          const double u = ((double)(c[2 * i] >> 5) * 67108864.0 + (double)(c[2 * i + 1] >> 6)) * (1.0 / 9007199254740992.0);
+          int sel = 0;
+          double acc = r[0];
+          for (int k = 1; k < K; ++k) { if (u >= acc) sel = k; acc += r[k]; }   // first k with u < cumulative sum; the last one catches the rest
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) cnt[k] += (sel == k) ? 1u : 0u;
+        }
+      }
+    }
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k) if (k < K && cnt[k] > cnt[best]) best = k;
+    out[t] = (uint8_t)best;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int fail(vmr_handle h, int code, const char* msg) {
-  if (h) h->err = msg; else g_create_err = msg;
-  return code;
-}
 
 static size_t shmem_ct(const Geo& g) { return g.mut ? (size_t)g.Mp * g.K * 8 : 0; }
 static size_t shmem_q() { return (size_t)(TPB / 64) * 64 * QCAP * 2; }
@@ -2654,15 +2368,25 @@ static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   return s;
 }
 
-struct Prof {
-  vmr_ctx* h; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-  Prof(vmr_ctx* h_, int c, hipStream_t st_ = nullptr) : h(h_), cls(c), st(st_ ? st_ : h_->stream) {
-    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-  }
-  ~Prof() {
-    if (h->prof) { (void)hipEventRecord(b, st); h->evs.push_back({cls, a, b}); }
-  }
-};
+
+// Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
+static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
+  const Geo& g = h->g;
+  SlShape s{h->sp_tpb, update ? g.yt : 0, hist ? g.hc : 0, 0};
+  auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
+  while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
+  s.smem = bytes();
+  return s;
+}
+static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
+  return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par, h->slotR,
+                h->lutg, h->Hg, h->slotF, h->slotA, h->Fg, 1, do_hist, sh.yt, sh.hc, sum_a};
+}
+static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
+  sl_launch_fn fn = vmr_sl_launcher(h->g.K);
+  if (!fn) return fail(h, VMR_EINVAL, "this build of libvimure_hip.so holds no sweep kernel for this K");
+  return fn(h, mode, sh, a);
+}
 
 #ifdef VMR_DEV   // development build: K = 2 only (fast compile, ISA inspection)
 #define DISPATCH_K(K_, ...)                         \
@@ -2691,26 +2415,6 @@ struct Prof {
     default: { constexpr int PP = 12; DISPATCH_K(K_, __VA_ARGS__); } break; \
   }
 
-// Opt in to > 48 KB of dynamic LDS and size the (persistent) grid to what is resident at once:
-// workgroups per layer = resident workgroups per CU x CUs / L, never more than tile pairs.
-template <class Kern>
-static int grid_per_layer(vmr_ctx* h, Kern k, size_t smem, int* gl, long long cap = 0, int tpb = TPB) {
-  const void* fn = reinterpret_cast<const void*>(k);
-  int per_cu = 0;
-  for (auto& e : h->occ) if (e.first == fn) per_cu = e.second;
-  if (!per_cu) {
-    if (smem > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, tpb, smem));
-    if (per_cu < 1) per_cu = 1;
-    h->occ.push_back({fn, per_cu});
-  }
-  long long gl_ = (long long)per_cu * h->ncu / h->g.L;
-  if (gl_ < 1) gl_ = 1;
-  if (cap <= 0) cap = h->g.P;
-  if (gl_ > cap) gl_ = cap;
-  *gl = (int)gl_;
-  return VMR_OK;
-}
 
 // k_fin_rho: nu and/or the ELBO; folds the NH copies of H into copy 0 on its way when they are not folded yet
 static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo) {
@@ -2762,6 +2466,15 @@ static int launch_hist(vmr_ctx* h) {
     h->f_valid = g.fuse_full != 0;
     if (g.ml) { int rc = begin_sum_a(h, h->stream); if (rc) return rc; h->a_valid = true; }
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
+    if (h->sl) {
+      const SlShape shs = sl_shape(h, false, false, true);
+      SlArgs as = sl_args(h, shs, 1, g.ml);
+      int rcs = sl_launch(h, 3, shs, as);
+      if (rcs) return rcs;
+      HIPCHK(h, hipGetLastError());
+      h->h_valid = true; h->h_zero = false; h->h_reduced = false;
+      return VMR_OK;
+    }
     const SpShape sh = sp_shape(h, false, false, true);
     SpArgs a = sp_args(h, sh, 1, g.ml);
     int rc = VMR_OK;
@@ -2819,15 +2532,15 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
       h->ml_attr = true;
     }
     DISPATCH_K(g.K, hipLaunchKernelGGL((k_mask_lists<KK>), dim3(g.L * gl), dim3(TPB), lsm, ms, h->rq, h->Rm, h->rbase,
-                                       h->rcls, h->rho, h->slotA, gl, g));
+                                       h->rcls, h->rho, h->slotA, gl, h->perm, g));
   } else if (!skip_full || h->n_partial > 0) {
     Prof p(h, VMR_KERNEL_GAMMA_MASK, ms);
     dim3 grid(g.L * g.Gm), blk(TPB);
     switch (g.W >= 4 ? 4 : g.W) {
-      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
-      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
-      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
-      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, g)); break;
+      case 1: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 1>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, h->perm, g)); break;
+      case 2: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 2>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, h->perm, g)); break;
+      case 3: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 3>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, h->perm, g)); break;
+      default: DISPATCH_K(g.K, hipLaunchKernelGGL((k_gamma_mask<KK, 4>), grid, blk, 0, ms, h->Rb, h->rho, h->rcls, h->slotA, skip_full, h->perm, g)); break;
     }
   }
   if (ms != h->stream) {
@@ -2898,6 +2611,11 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     const int sum_a = (g.ml && do_hist) ? 1 : 0;   // (two passes: the statistics pass that follows sums the lists)
     if (mode != 2) h->a_valid = false;
     if (sum_a) { if ((rc = begin_sum_a(h, h->stream))) return rc; h->a_valid = true; }
+    if (h->sl) {
+      const SlShape shs = sl_shape(h, mode != 2, mode != 0, do_hist != 0);
+      SlArgs as = sl_args(h, shs, do_hist, sum_a);
+      if ((rc = sl_launch(h, mode, shs, as))) return rc;
+    } else {
     const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
     SpArgs s = sp_args(h, sh, do_hist, sum_a);
 #define LSP2(MUT_, UPD_, ELB_, LG_)                                                            \
@@ -2911,6 +2629,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     }
 #undef LSP
 #undef LSP2
+    }
   } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
@@ -2983,7 +2702,6 @@ const char* vmr_last_error(vmr_handle h) { return h ? h->err.c_str() : g_create_
 // ------------------------------------------------------------------------------------------
 // vmr_create / vmr_create_coo
 // ------------------------------------------------------------------------------------------
-#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); return VMR_EHIP; } } while (0)
 
 // context, geometry, streams and the small per-dataset arrays
 static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, int N, int M, int K, int mutuality, double eps) {
@@ -3009,6 +2727,7 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
   h->ncu = prop->multiProcessorCount;
   h->serial = getenv("VMR_SERIAL") != nullptr;
   h->use_graphs = getenv("VMR_GRAPH") != nullptr;   // off by default, see vmr_ctx::graphs
+  { const char* lf = getenv("VMR_LISTS"); h->sl = (lf && !strcmp(lf, "steps")) ? 0 : 1; }   // sorted report lists unless the older step layout is asked for
   const size_t rows = (size_t)L * N * N;
   CK(hipMalloc(&h->cov, rows));
   CK(hipMalloc(&h->rcls, rows));
@@ -3049,7 +2768,7 @@ static int create_state(vmr_ctx* h, unsigned* xm_out) {
   return VMR_OK;
 }
 
-static int scan_u32(vmr_ctx* h, unsigned* a, unsigned* bsum, size_t n) {
+int scan_u32(vmr_ctx* h, unsigned* a, unsigned* bsum, size_t n) {
   const unsigned nb = (unsigned)((n + 2047) / 2048);
   hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, h->stream, a, bsum, n);
   hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(256), 0, h->stream, bsum, (int)nb);
@@ -3162,6 +2881,24 @@ static int mask_lists_from_words(vmr_ctx* h) {
   return VMR_OK;
 }
 
+// sorted lists: the per-tie arrays the sweeps read, by position (the tie-order originals stay for the mask kernels)
+static int sl_finish(vmr_ctx* h) {
+  const Geo& g = h->g;
+  const size_t rows = (size_t)g.L * g.N * g.N;
+  int rc = VMR_OK;
+  if (!h->all_full) {
+    CK(hipMalloc(&h->cls_p, rows));
+    if ((rc = sl_permute_u8(h, h->rcls, h->cls_p))) return rc;
+  }
+  if (g.mut && h->Qt) {
+    CK(hipMalloc(&h->Qt_p, rows * 4));
+    if ((rc = sl_permute_u32(h, h->Qt, h->Qt_p))) return rc;
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipFree(h->Qt)); h->Qt = nullptr;   // (only the sweeps read it)
+  }
+  return VMR_OK;
+}
+
 // LDS shapes, the statistics / factor tables, scratch; for report lists the count-mode launch (constants C[l][y][m])
 static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
@@ -3174,7 +2911,46 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   g.yt = 0;
   g.two_pass = 0;
   size_t need = 0;
-  if (h->sparse) {
+  if (h->sparse && h->sl) {
+    // Sorted lists: the populous levels of F (read) and H (float atomics) in LDS, shared by all waves of a workgroup; no per-wave
+    // LDS at all.  One pass per sweep when at least 4 levels of each fit at >= 16 waves per CU, else the rho pass keeps F and a
+    // statistics pass rebuilds H (two passes over the entries).
+    auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 12)));
+    auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {
+      const size_t b = sl_smem(g, yt, hc, upd, false, hist);
+      if (b > SP_LDS_MAX) return 0;
+      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), 32 / nw);
+      return wgs * nw;
+    };
+    auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {
+      for (int lv = want; lv >= 1; --lv) {
+        int bw = 0, bt = 256;
+        for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
+        if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
+      }
+      return false;
+    };
+    int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
+    const bool one = best(true, true, 16, lv1, t1);
+    if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
+    else {
+      g.two_pass = 1;
+      if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
+      if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
+      g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
+    }
+    {   // small datasets: smaller workgroups, so that the steps spread over every CU
+      const long long NS = ((long long)g.N * g.N + 63) / 64;
+      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb >>= 1;
+    }
+    if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
+    g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
+    g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
+    { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
+    for (int v = 0; v < 4; ++v) need = std::max(need, sl_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
+    CK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
+  } else if (h->sparse) {
     // Report lists: both tables want the populous levels in LDS ([level][Mp][K] doubles each) beside 64 K doubles per
     // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
     // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
@@ -3240,11 +3016,17 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   if (h->sparse) {
     // the constants C[l][y][m] = sum of the counts per (mirror count, reporter): one statistics launch in count mode
     CK(hipMalloc(&h->Cg, (size_t)L * g.Y * g.Mp * 8));
-    const SpShape sh = sp_shape(h, false, false, true);
-    SpArgs a = sp_args(h, sh, 2);
     int rc = VMR_OK;
-    DISPATCH_K(g.K, rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb);
-               if (rc == VMR_OK) hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
+    if (h->sl) {
+      const SlShape sh = sl_shape(h, false, false, true);
+      SlArgs a = sl_args(h, sh, 2);
+      rc = sl_launch(h, 3, sh, a);
+    } else {
+      const SpShape sh = sp_shape(h, false, false, true);
+      SpArgs a = sp_args(h, sh, 2);
+      DISPATCH_K(g.K, rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb);
+                 if (rc == VMR_OK) hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
+    }
     if (rc != VMR_OK) { g_create_err = h->err; return rc; }
     CK(hipGetLastError());
     const size_t nit = (size_t)L * g.Y * g.Mp;
@@ -3287,7 +3069,8 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
   // ---- data format: report lists unless X is dense enough that 1 B per (tie, reporter) is less to read ----
   const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
   const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
-  const bool can_list = g.Mp <= 8192 && xm <= ENT_CMAX;   // 13-bit reporter field, 6-bit counts
+  // 13-bit reporter field; the sorted lists hold counts <= 2047 and (max count + 1) * Mp <= 2^20 table rows, the step layout counts <= 63
+  const bool can_list = g.Mp <= 8192 && (h->sl ? (xm <= SL_XMAX && (size_t)(xm + 1) * g.Mp <= SL_YM_ROWS) : xm <= ENT_CMAX);
   if (!force_dense && can_list) {
     unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
     CK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
@@ -3311,14 +3094,21 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
     if (h->sparse) {
       CK(hipMalloc(&h->Qt, rows * 4));
       CK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-      rc = place_entries(h, rp, nl, nullptr, [&](int l, const unsigned* rpl, unsigned* etmp) {
+      auto fill_layer = [&](int l, const unsigned* rpl, unsigned* etmp) {
         if (g.mut)
           hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, h->sl, g);
         else
           hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
-      });
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, h->sl, g);
+      };
+      if (h->sl) {
+        const SlFill ff = fill_layer;
+        rc = sl_place_entries(h, rp, nl, nullptr, &ff);
+        if (!rc) rc = sl_finish(h);
+      } else {
+        rc = place_entries(h, rp, nl, nullptr, fill_layer);
+      }
       if (!rc) rc = mask_lists_from_words(h);
       if (!rc && !getenv("VMR_KEEP_X")) { CK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
     }
@@ -3404,14 +3194,15 @@ __global__ void k_coo_class(const unsigned* __restrict__ cx, const unsigned* __r
 template <bool MUT>
 __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const unsigned* __restrict__ vx, long long nx,
                               const unsigned long long* __restrict__ kr, long long nr /* < 0: all ones */, int N, int Mp,
-                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad) {
+                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad,
+                              int sl) {
   unsigned long long s = 0;
   unsigned mx = 0;
   const unsigned long long T = (unsigned long long)N * N;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (long long)gridDim.x * blockDim.x) {
     const unsigned long long key = kx[e], tie = key >> 13, l = tie / T, t = tie - l * T, i = t / N, j = t - i * N;
     const unsigned m = (unsigned)(key & 0x1fffu), x = vx[e];
-    if (x == 0u || x > ENT_CMAX) { atomicOr(bad, 4); continue; }
+    if (x == 0u || x > (sl ? SL_XMAX : ENT_CMAX)) { atomicOr(bad, 4); continue; }
     s += x; mx = max(mx, x);
     const unsigned long long tm = l * T + j * N + i;
     unsigned y = 0;
@@ -3421,7 +3212,8 @@ __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const u
       if (nr < 0 || coo_find(kr, nr, COO_KEY(tm, m)) >= 0) atomicAdd(&Qt[tm], x);   // R[mirror, m] X[this, m]
     }
     const unsigned inr = (nr < 0 || coo_find(kr, nr, key) >= 0) ? 1u : 0u;
-    etmp[e] = (y * (unsigned)Mp + m) | (inr << 19) | ((unsigned)(t & 63) << 20) | (x << 26);
+    etmp[e] = sl ? ((y * (unsigned)Mp + m) | (inr << 20) | (x << 21))
+                 : ((y * (unsigned)Mp + m) | (inr << 19) | ((unsigned)(t & 63) << 20) | (x << 26));
   }
   if (s) atomicAdd(sumx, s);
   if (mx) atomicMax(xmax, mx);
@@ -3549,8 +3341,8 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   CKC(hipMalloc(&etmp, ((size_t)nx + 64) * 4));
   CKC(hipMalloc(&h->Qt, rows * 4));
   CKC(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
-  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
+  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev, h->sl);
+  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev, h->sl);
   CKC(hipGetLastError());
   CKC(hipStreamSynchronize(h->stream));
   int bad = 0;
@@ -3561,7 +3353,8 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     cleanup();
     return fail(nullptr, VMR_EINVAL, (bad & 1) ? "a subscript lies outside (L, N, N, M)"
                                    : (bad & 2) ? "duplicate (l, i, j, m) subscripts"
-                                               : "counts must lie in [1, 63] for the report lists (use vmr_create for larger counts)");
+                                               : (h->sl ? "counts must lie in [1, 2047] for the report lists"
+                                                        : "counts must lie in [1, 63] for the report lists (use vmr_create for larger counts)"));
   }
   unsigned xmv = 0;
   if ((rc = create_state(h, &xmv))) { cleanup(); return rc; }
@@ -3580,7 +3373,12 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     CKC(e1);
     for (int l = 0; l < L; ++l) nl[l] = st[l + 1] - st[l];
   }
-  rc = place_entries(h, cx, nl, etmp, [](int, const unsigned*, unsigned*) {});
+  if (h->sl && (size_t)(xmv + 1) * g.Mp > SL_YM_ROWS) {
+    cleanup();
+    return fail(nullptr, VMR_EINVAL, "(largest count + 1) * M exceeds the 2^20 table rows of the report lists");
+  }
+  if (h->sl) { rc = sl_place_entries(h, cx, nl, etmp, nullptr); if (!rc) rc = sl_finish(h); }
+  else rc = place_entries(h, cx, nl, etmp, [](int, const unsigned*, unsigned*) {});
   if (rc) { cleanup(); return rc; }
   // the mask: all ones needs nothing; partial rows become mask lists when they are short, bit-packed words otherwise
   if (nr >= 0 && h->n_partial > 0) {
@@ -3643,7 +3441,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3719,12 +3517,22 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   if ((rc = h2d(h, h->par + o.sc + SC_NU_SHP, nu, 16))) return rc;   // (the stream is synchronised below, before nu[] dies)
   const size_t n = (size_t)g.L * g.N * g.N * g.K;
   const double* src = pr_rho;
-  if (!pr_rho_on_device) {
-    // stage through logpr (overwritten by k_init_rho element-wise after being read)
-    HIPCHK(h, hipMemcpyAsync(h->logpr, pr_rho, n * 8, hipMemcpyHostToDevice, h->stream));
-    src = h->logpr;
+  if (h->perm) {   // sorted lists: rho and the log prior are stored by position
+    if (!pr_rho_on_device) {
+      if (!h->nat) HIPCHK(h, hipMalloc(&h->nat, n * 8));
+      HIPCHK(h, hipMemcpyAsync(h->nat, pr_rho, n * 8, hipMemcpyHostToDevice, h->stream));
+      src = h->nat;
+    }
+    const size_t T_ = (size_t)g.N * g.N;
+    hipLaunchKernelGGL(k_init_rho_pos, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, h->perm, T_, (T_ + 63) / 64, g.L, g.K, g.eps);
+  } else {
+    if (!pr_rho_on_device) {
+      // stage through logpr (overwritten by k_init_rho element-wise after being read)
+      HIPCHK(h, hipMemcpyAsync(h->logpr, pr_rho, n * 8, hipMemcpyHostToDevice, h->stream));
+      src = h->logpr;
+    }
+    hipLaunchKernelGGL(k_init_rho, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, n, g.eps);
   }
-  hipLaunchKernelGGL(k_init_rho, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, n, g.eps);
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_derive_all, dim3(8), dim3(256), 0, h->stream, h->par, g);
   HIPCHK(h, hipGetLastError());
@@ -3732,9 +3540,11 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
+  h->restored = false;
   h->h_valid = false;
   h->f_valid = false;
   h->a_valid = false;
+  h->ftab_valid = false; h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   return VMR_OK;
 }
@@ -3783,6 +3593,7 @@ static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
 int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_step");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_step after vmr_restore: the restored state is read-only until the next vmr_set_state");
   if (n_iters < 0) return fail(h, VMR_EINVAL, "n_iters < 0");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
@@ -3815,6 +3626,7 @@ int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, 
                  double* row_runtime, int* row_reached, double* elbo_out, int* iters_out, int* converged_out) {
   if (!h || !n_rows || !elbo_out || !iters_out || !converged_out) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_fit_loop");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_fit_loop after vmr_restore: the restored state is read-only until the next vmr_set_state");
   if (cap > 0 && (!row_iter || !row_elbo || !row_runtime || !row_reached)) return fail(h, VMR_EINVAL, "trace arrays missing");
   int coincide = 0, it = 1, reached = 0, rows = 0, rc;
   double elbo = -1e10;   // INF of the reference (model.py:24)
@@ -3846,6 +3658,7 @@ int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, 
 int vmr_elbo(vmr_handle h, double* out) {
   if (!h || !out) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_elbo");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_elbo after vmr_restore: the restored state is read-only until the next vmr_set_state");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   if ((rc = launch_rho(h, 2, false))) return rc;
@@ -3855,6 +3668,7 @@ int vmr_elbo(vmr_handle h, double* out) {
 int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   if (!h || !out3) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sweep_local");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_sweep_local after vmr_restore: the restored state is read-only until the next vmr_set_state");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;
@@ -3873,14 +3687,40 @@ int vmr_commit_nu(vmr_handle h, double nu_partial_total) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_commit_nu");
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_commit_nu, dim3(1), dim3(64), 0, h->stream, h->par, nu_partial_total, h->g);
+  hipLaunchKernelGGL(k_commit_nu, dim3(1), dim3(64), 0, h->stream, h->par, nu_partial_total, (const double*)nullptr, h->g);
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
 }
 
+// the same exchange with the three doubles left on the device (RCCL all-reduce on the handle's stream, see vmr_stream)
+int vmr_sweep_local_dev(vmr_handle h, int want_elbo, double* out3_dev) {
+  if (!h || !out3_dev) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sweep_local_dev");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_sweep_local_dev after vmr_restore: the restored state is read-only until the next vmr_set_state");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = launch_gamma(h, true))) return rc;
+  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;
+  if (!want_elbo && (rc = launch_fin_rho(h, 0, 0))) return rc;
+  HIPCHK(h, hipMemcpyAsync(out3_dev, h->elbo_dev + 1, 24, hipMemcpyDeviceToDevice, h->stream));
+  return VMR_OK;
+}
+
+int vmr_commit_nu_dev(vmr_handle h, const double* nu_partial_total_dev) {
+  if (!h || !nu_partial_total_dev) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_commit_nu_dev");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_commit_nu, dim3(1), dim3(64), 0, h->stream, h->par, 0.0, nu_partial_total_dev, h->g);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+
+void* vmr_stream(vmr_handle h) { return h ? (void*)h->stream : nullptr; }
+
 int vmr_sub_step(vmr_handle h, int which) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sub_step");
+  if (h->restored) return fail(h, VMR_ESTATE, "vmr_sub_step after vmr_restore: the restored state is read-only until the next vmr_set_state");
   HIPCHK(h, hipSetDevice(h->device));
   switch (which) {
     case VMR_STEP_GAMMA: return launch_gamma(h, false);
@@ -3919,7 +3759,16 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
   if (phi_rte && (rc = d2h(h, phi_rte, h->par + o.p_rte, (size_t)g.L * g.K * 8))) return rc;
   if (nu_shp && (rc = d2h(h, nu_shp, h->par + o.sc + SC_NU_SHP, 8))) return rc;
   if (nu_rte && (rc = d2h(h, nu_rte, h->par + o.sc + SC_NU_RTE, 8))) return rc;
-  if (rho && (rc = d2h(h, rho, h->rho, (size_t)g.L * g.N * g.N * g.K * 8))) return rc;
+  if (rho) {
+    const size_t nr = (size_t)g.L * g.N * g.N * g.K;
+    const double* src = h->rho;
+    if (h->perm) {   // back to tie order
+      if (!h->nat) HIPCHK(h, hipMalloc(&h->nat, nr * 8));
+      if ((rc = sl_permute_rows(h, h->rho, h->nat, false))) return rc;
+      src = h->nat;
+    }
+    if ((rc = d2h(h, rho, src, nr * 8))) return rc;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return VMR_OK;
 }
@@ -3962,6 +3811,7 @@ int vmr_restore(vmr_handle h) {
   HIPCHK(h, hipMemcpyAsync(h->rho, h->rho_snap, (size_t)g.L * g.N * g.N * g.K * 8, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->par, h->par_snap, h->par_doubles * 8, hipMemcpyDeviceToDevice, h->stream));
   h->h_valid = false; h->f_valid = false; h->a_valid = false; h->ftab_valid = false; h->h_zero = false;
+  h->restored = true;   // the log prior on the device is the LAST realisation's: reading is fine, sweeping is not
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
@@ -3977,13 +3827,33 @@ int vmr_readout(vmr_handle h, int method, double threshold, void* out, int out_o
   const size_t ties = (size_t)g.L * g.N * g.N, bytes = ties * (method == VMR_READ_RHO_MEAN ? 8 : 1);
   void* dst = out;
   if (!out_on_device) HIPCHK(h, hipMalloc(&dst, bytes));
+  const size_t T_ = (size_t)g.N * g.N;
   hipLaunchKernelGGL(k_readout, dim3((unsigned)std::min<size_t>(4096, (ties + 255) / 256)), dim3(256), 0, h->stream, h->rho, dst, ties,
-                     g.K, method, threshold);
+                     g.K, method, threshold, h->perm, T_, (T_ + 63) / 64);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (!out_on_device) (void)hipFree(dst);
   if (e != hipSuccess) { h->err = std::string("vmr_readout: ") + hipGetErrorString(e); (void)hipGetLastError(); return VMR_EHIP; }
+  return VMR_OK;
+}
+
+int vmr_sample(vmr_handle h, uint64_t seed, int n_trials, uint8_t* out, int out_on_device) {
+  if (!h || !out) return VMR_EINVAL;
+  if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sample");
+  if (n_trials < 1) return fail(h, VMR_EINVAL, "n_trials must be positive");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Geo& g = h->g;
+  const size_t T_ = (size_t)g.N * g.N, ties = (size_t)g.L * T_;
+  uint8_t* dst = out;
+  if (!out_on_device) HIPCHK(h, hipMalloc(&dst, ties));
+  hipLaunchKernelGGL(k_sample, dim3((unsigned)std::min<size_t>(4096, (ties + 255) / 256)), dim3(256), 0, h->stream, h->rho, dst, ties, g.K,
+                     n_trials, (unsigned long long)seed, h->perm, T_, (T_ + 63) / 64);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, dst, ties, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (!out_on_device) (void)hipFree(dst);
+  if (e != hipSuccess) { h->err = std::string("vmr_sample: ") + hipGetErrorString(e); (void)hipGetLastError(); return VMR_EHIP; }
   return VMR_OK;
 }
 
@@ -4046,7 +3916,8 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   const double SX = V, SR = V / 8.0, Srho = 8.0 * g.L * (double)g.N * g.N * g.K;
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
-    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (2.0 * ties / 64.0 + g.L);   // entries (without the rounds' padding); step pointers
+    // entries (without the rounds' padding); step pointers: two per 64 ties in the step layout, one in the sorted lists
+    const double E = 4.0 * (double)h->nnz, RP = 4.0 * ((h->sl ? 1.0 : 2.0) * ties / 64.0 + g.L);
     const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {

@@ -81,7 +81,7 @@ class CaviEngine:
     def from_coo(cls, subs, vals, shape, R=None, K=2, mutuality=True, eps=1e-12, device=None):
         """Dataset from coordinate lists -- the reference's own containers (`X.subs`, `X.vals`, `R.subs`; reference
         model.py:136-171) -- without a dense [L,N,N,M] tensor on the host or the device (vmr_create_coo).
-        subs: 4 index arrays (l, i, j, m); vals: counts in [1, 63]; R: None (every reporter may report on every tie) or 4
+        subs: 4 index arrays (l, i, j, m); vals: counts in [1, 2047]; R: None (every reporter may report on every tie) or 4
         index arrays of the mask's non-zeros; NumPy arrays or torch GPU tensors (int32 / int64)."""
         self = cls.__new__(cls)
         self._h = C.c_void_p()
@@ -249,6 +249,32 @@ class CaviEngine:
 
     def commit_nu(self, nu_partial_total):
         self._check(self.lib.vmr_commit_nu(self._h, float(nu_partial_total)))
+
+    def stream_ptr(self):
+        """The handle's hipStream_t (for collectives queued between the engine's kernels: torch.cuda.ExternalStream)."""
+        return int(self.lib.vmr_stream(self._h) or 0)
+
+    def sweep_local_dev(self, out3, want_elbo=False):
+        """`sweep_local` that leaves (nu_partial, elbo_main, elbo_q) in the float64 CUDA tensor `out3` (3 elements),
+        asynchronously on the engine's stream."""
+        assert out3.is_cuda and out3.numel() >= 3 and out3.is_contiguous()
+        self._check(self.lib.vmr_sweep_local_dev(self._h, int(want_elbo), out3.data_ptr()))
+
+    def commit_nu_dev(self, total):
+        """`commit_nu` from a float64 CUDA tensor holding the summed nu partial in element 0 (no host hop)."""
+        self._check(self.lib.vmr_commit_nu_dev(self._h, total.data_ptr()))
+
+    def sample(self, seed, n_trials=1, out=None):
+        """One posterior sample of Y [L,N,N] uint8 drawn on the device from the current rho: per tie the most frequent
+        category of n_trials categorical trials (`Generator.multinomial(n_trials, rho).argmax(-1)`, reference
+        model.py:1062-1096), Philox stream keyed by `seed`.  out: a uint8 CUDA tensor to keep the sample on the device."""
+        if out is not None:
+            assert out.is_cuda and out.is_contiguous() and out.numel() == self.L * self.N * self.N
+            self._check(self.lib.vmr_sample(self._h, int(seed) & (2 ** 64 - 1), int(n_trials), out.data_ptr(), 1))
+            return out
+        y = np.empty((self.L, self.N, self.N), np.uint8)
+        self._check(self.lib.vmr_sample(self._h, int(seed) & (2 ** 64 - 1), int(n_trials), y.ctypes.data, 0))
+        return y
 
     def sub_step(self, which):
         self._check(self.lib.vmr_sub_step(self._h, int(which)))

@@ -81,7 +81,7 @@ class VimureModel(TransformerMixin, BaseEstimator):
         # a coordinate container (the reference's sptensor surface: subs / vals / shape) goes to the device as it is
         # (vmr_create_coo) when the report lists can hold it; no dense [L,N,N,M] array is built then
         coo = (not dev_tensor and is_sparse_like(X) and not self.undirected and extra.get("engine") is None
-               and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 63)))
+               and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 2047)))
         if dev_tensor or coo or (extra.get("engine") is not None and is_sparse_like(X)):
             Xd = X   # (with `engine` the data is on the device already: only the shape is needed)
             shape = tuple(int(s) for s in X.shape)
@@ -303,21 +303,47 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 import queue
                 import threading
                 q = queue.Queue(maxsize=1)   # one finished state waits while the next is drawn (three staging buffers)
+                stop = threading.Event()     # set on any exit from fit(): the producer draws nothing further
+                # upload-ahead keeps two device slots in rotation: slot r % 2 may only be overwritten once set_state(r) has
+                # consumed it (set_state synchronises the engine's stream before it returns)
+                slot_free = [threading.Event(), threading.Event()]
+                for ev in slot_free:
+                    ev.set()
+
+                def put(item):
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            return True
+                        except queue.Full:
+                            continue
+                    return False
 
                 def work():
                     try:
                         for item in states:
+                            if stop.is_set():
+                                return
                             r_ = item[0]
                             pr_ = item[2]["pr_rho"]
                             si = self._staging_index(eng, r_)
                             if r_ > 0 and getattr(eng, "can_upload_ahead", lambda: False)() and isinstance(pr_, np.ndarray) and np.shares_memory(pr_, eng.staging(si)):
-                                dev = eng.upload_ahead(si, r_ % 2)   # (realisation 0 is waited for: nothing to hide its upload behind)
+                                slot = r_ % 2
+                                while not slot_free[slot].wait(timeout=0.1):
+                                    if stop.is_set():
+                                        return
+                                slot_free[slot].clear()
+                                dev = eng.upload_ahead(si, slot)   # (realisation 0 is waited for: nothing to hide its upload behind)
                                 if dev is not None:
                                     item[2]["pr_rho"] = dev
-                            q.put(item)
-                        q.put(None)
+                                    item[2]["_slot"] = slot
+                                else:
+                                    slot_free[slot].set()
+                            if not put(item):
+                                return
+                        put(None)
                     except BaseException as e:   # surfaces in the consumer
-                        q.put(e)
+                        put(e)
                 producer = threading.Thread(target=work, daemon=True)
                 producer.start()
 
@@ -339,6 +365,8 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 r, seed_r, st, final_seed = item
                 eng.set_state(st["gamma_shp"], st["gamma_rte"], st["phi_shp"], st["phi_rte"], st["nu_shp"], st["nu_rte"],
                               st["pr_rho"])   # (synchronises: the staging buffer is free again)
+                if "_slot" in st:   # the device slot of upload_ahead has been read: the producer may reuse it
+                    slot_free[st["_slot"]].set()
                 t_loop = time.perf_counter()
                 if not self.verbose:   # the whole loop on the engine's side (vmr_fit_loop): one call per realisation
                     rows, elbo, _, _ = eng.fit_loop(self.max_iter, self.convergence_tol, self.decision)
@@ -360,12 +388,14 @@ class VimureModel(TransformerMixin, BaseEstimator):
             if keep:
                 self._engine, own_engine = eng, False
         finally:
-            if producer is not None and producer.is_alive():   # an exception left the producer blocked on its queue
-                try:
-                    while producer.is_alive():
-                        q.get(timeout=0.1)
-                except Exception:
-                    pass
+            if producer is not None:   # stop the producer and wait for it BEFORE the engine (and its staging buffers) go away
+                stop.set()
+                while producer.is_alive():
+                    try:
+                        q.get(timeout=0.05)
+                    except queue.Empty:
+                        pass
+                producer.join()
             if own_engine:
                 eng.close()
         cols = ["realisation", "seed", "iter", "elbo", "runtime", "reached_convergence"]
@@ -463,9 +493,18 @@ class VimureModel(TransformerMixin, BaseEstimator):
                 pass
 
     # ------------------------------------------------------------------ read-out (model.py:1062-1214)
-    def sample_inferred_model(self, N=1, seed=None):
+    def sample_inferred_model(self, N=1, seed=None, device=False):
+        """Reference model.py:1062-1096: N samples of Y, sample i = `default_rng(seed + i).multinomial(N, rho_f).argmax(-1)`.
+        device=True (after `fit(keep_engine=True)`): the same draw on the GPU from the rho kept there (vmr_sample) -- per tie
+        the most frequent category of N categorical trials, a Philox stream keyed by seed + i instead of NumPy's PCG64 (same
+        distribution, reproducible for a seed, different numbers) -- so rho (8 L N^2 K bytes) never crosses PCIe."""
         if seed is None:
             seed = self.seed
+        if device:
+            eng = getattr(self, "_engine", None)
+            if eng is None:
+                raise ValueError("device=True needs the posteriors on the GPU: fit(..., keep_engine=True)")
+            return [eng.sample(seed + i, n_trials=N).astype(np.int64) for i in range(N)]
 
         def sample_y(s):
             g = np.random.default_rng(s)

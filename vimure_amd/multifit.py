@@ -52,7 +52,9 @@ def send_arrays_to_root(arrays: Dict[str, np.ndarray], owner: int, dist, device=
     meta = [names, [arrays[n].shape for n in names]] if rank == owner else None
     box = [meta]
     if rank == owner:
-        dist.send_object_list(box, dst=0) if hasattr(dist, "send_object_list") else None
+        if not hasattr(dist, "send_object_list"):   # (rank 0 would block forever in recv_object_list)
+            raise RuntimeError("torch.distributed.send_object_list is missing: torch >= 1.8 is required for the posterior hand-over")
+        dist.send_object_list(box, dst=0)
         for n in names:
             dist.send(torch.as_tensor(np.ascontiguousarray(arrays[n], dtype=np.float64), device=device).reshape(-1), dst=0)
         return {}

@@ -474,17 +474,26 @@ class PosteriorSyntheticNetwork:
     """Posterior predictive data (reference synthetic.py:964-1177): Y ~ Categorical(rho_f) of a fitted model, then X from
     theta, lambda, eta drawn from their Gamma posteriors, with the draw structure of `_build_X`."""
 
-    def __init__(self, model, seed_Y):
+    def __init__(self, model, seed_Y, device=False):
+        """device=True (model fitted with keep_engine=True): Y is drawn on the GPU from the rho kept there (vmr_sample, a
+        Philox stream keyed by seed_Y: same distribution as the exact NumPy mode, different numbers); rho_f is not copied."""
         self.prng = np.random.default_rng(seed_Y)
-        self.rho = model.rho_f
+        self._engine = getattr(model, "_engine", None) if device else None
+        if device and self._engine is None:
+            raise ValueError("device=True needs the posteriors on the GPU: fit(..., keep_engine=True)")
+        self.seed_Y = seed_Y
+        self.rho = None if self._engine is not None else model.rho_f
         self.theta_shp, self.theta_rte = model.gamma_shp_f, model.gamma_rte_f
         self.lambda_shp, self.lambda_rte = model.phi_shp_f, model.phi_rte_f
         self.mutuality_shp, self.mutuality_rte = model.nu_shp_f, model.nu_rte_f
-        self.L, self.N, _, self.K = self.rho.shape
+        self.L, self.N, self.K = model.L, model.N, model.K
         self.M = self.theta_shp.shape[1]
 
     def build_Y(self):
-        Y = self.prng.multinomial(n=1, pvals=self.rho, size=(self.L, self.N, self.N)).argmax(axis=-1)
+        if self._engine is not None:
+            Y = self._engine.sample(self.seed_Y, n_trials=1).astype(np.int64)
+        else:
+            Y = self.prng.multinomial(n=1, pvals=self.rho, size=(self.L, self.N, self.N)).argmax(axis=-1)
         Y[Y > self.K - 1] = self.K - 1
         self.Y = SparseTensor.fromarray(Y)
 
