@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4", "c5"])
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps sweeps; value = the median block")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (roofline then has no live launch time)")
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_layer / small_fits blocks after the timed region")
     ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra blocks")
     ap.add_argument("--villages", type=int, default=16, help="--config c4: synthetic villages (x 4 layers x --seeds fits)")
@@ -148,7 +149,8 @@ def main():
 
     run(1, args.warmup)
     eng.sync()
-    eng.profile(True)
+    if not args.no_kernel_events:
+        eng.profile(2)   # events around the passes over the data only (the roofline kernels), not the finalize kernels
     blocks = []
     elbo = None
     it0 = args.warmup + 1

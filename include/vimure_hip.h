@@ -197,7 +197,8 @@ int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g
 int vmr_sync(vmr_handle h);
 
 /* Per-kernel-class timing with HIP events on the handle's stream (for bench.py's roofline
- * line).  enable=1 starts recording and clears totals. vmr_profile_read synchronises. */
+ * line).  enable=1 starts recording and clears totals; enable=2 records only the passes over the data (classes
+ * GAMMA_COUNTS, RHO, ELBO, RHO_ELBO), not the small finalize kernels.  vmr_profile_read synchronises. */
 int vmr_profile(vmr_handle h, int enable);
 int vmr_profile_read(vmr_handle h, int kernel_class, double* total_ms, int64_t* launches);
 

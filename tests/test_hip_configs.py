@@ -206,12 +206,13 @@ def test_long_steps_two_categories(mask, monkeypatch):
 def test_config5_layer_at_stated_size():
     """BASELINE configs[4] as stated -- L=8, N=8000, M=1000, K=3, one layer per GPU: ONE GPU's share (a 64 GB layer generated on
     the device, 1.2 G reports) through a sweep, checked by properties that need no 200-second oracle build:
-      * every tie's rho sums to 1 (model.py:808-811);
+      * every tie's rho sums to 1 or -- where the reference's raw exponentials all underflow, which with 1000 reporters' worth
+        of E[theta] in the exponent happens at the first sweeps -- is left all zero (model.py:807-811);
       * rho of 20 000 sampled ties recomputed on the host from the engine's own gamma / phi / nu and those ties' reports -- the
         rho update is per tie given the parameter tables (model.py:795-811, 889-923);
       * gamma_rte from the all-ones mask sums of the prior (model.py:704-718);
-      * the mass identity sum_m (gamma_shp - alpha) + (nu partial) = sum(X) at fixed parameters and rho: w1 + w2 = 1 per report
-        (model.py:685-696), i.e. every one of the layer's reports was counted exactly once by the statistics;
+      * the mass identity sum_m (gamma_shp - alpha) + (nu partial) = sum over reports of x sum_k rho_k at fixed parameters and
+        rho: w1 + w2 = 1 per report (model.py:685-696), i.e. every one of the layer's reports was counted exactly once;
       * the ELBO fused into the sweep equals the stand-alone one (model.py:948-1019).
     The N=1500 oracle test above stays the bit-level check of this regime."""
     import scipy.special as sp
@@ -232,7 +233,9 @@ def test_config5_layer_at_stated_size():
     st = eng.get_state(rho=True)
     rho = st["rho"]
     assert np.isfinite(rho).all()
-    assert np.abs(rho.sum(axis=-1) - 1.0).max() < 1e-12
+    rsum = rho.sum(axis=-1)
+    zero_rows = (rho == 0.0).all(axis=-1)   # every exp(a_k) underflowed: left unnormalised, as the reference does
+    assert np.abs(rsum[~zero_rows] - 1.0).max() < 1e-12
     assert st["nu_shp"] == nu_shp0   # (not committed)
     # gamma_rte = beta + sum_k E[lambda_k]_old sum_t pr_rho_k: the mask is all ones (the pass that sums rho over ties)
     S0 = pr.reshape(-1, K).sum(axis=0)
@@ -262,7 +265,9 @@ def test_config5_layer_at_stated_size():
     # mass identity at fixed parameters and rho: the gamma sub-step now uses the same theta, lambda, nu and rho as nu_part did
     eng.sub_step(_lib.STEP_GAMMA)
     g2 = eng.get_state(rho=False)["gamma_shp"][0]
-    assert abs((g2 - PRI[0]).sum() + nu_part - sum_x) <= 1e-10 * sum_x, ((g2 - PRI[0]).sum(), nu_part, sum_x)
+    xt = torch.cat([net.X[0, i0:i0 + 200].sum(dim=-1, dtype=torch.int64) for i0 in range(0, N, 200)]).cpu().numpy()   # reports per tie
+    mass = float((xt * rsum[0]).sum())
+    assert abs((g2 - PRI[0]).sum() + nu_part - mass) <= 1e-10 * sum_x, ((g2 - PRI[0]).sum(), nu_part, mass, sum_x)
     # a fused sweep + ELBO at full size, against the stand-alone ELBO pass
     eng.set_state(*init)
     e1 = eng.step(2, want_elbo=True)

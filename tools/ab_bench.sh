@@ -5,7 +5,7 @@ OUT=$1; shift
 mkdir -p $OUT
 for spec in "$@"; do
   name=${spec%%|*}; envs=${spec#*|}
-  ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done
+  ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
     timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-converge ${BENCH_ARGS} > $OUT/$name.log 2>&1
     echo "rc=$?" >> $OUT/$name.log )
   python3 - "$OUT/$name.log" "$name" <<'PY'

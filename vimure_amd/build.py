@@ -47,17 +47,21 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+    """VMR_CXXFLAGS adds compiler flags (kernel experiments: -DSL_WPE=5 ...), VMR_TAG keeps such a build's objects apart
+    (csrc/_obj/<tag>), VMR_LIB_OUT names the library -- tools/ab_bench.sh picks builds with VMR_LIB."""
+    tagged = bool(os.environ.get("VMR_TAG"))
+    if not force and not tagged and not needs_build():
         return LIB
     dev = bool(os.environ.get("VMR_DEV"))
-    odir = os.path.join(OBJ, "dev" if dev else "full")
+    odir = os.path.join(OBJ, os.environ.get("VMR_TAG") or ("dev" if dev else "full"))
+    more = os.environ.get("VMR_CXXFLAGS", "").split()
     os.makedirs(odir, exist_ok=True)
     todo, objs = [], []
     for name, src, extra in units(dev):
         obj = os.path.join(odir, name + ".o")
         objs.append(obj)
         if force or _stale(obj, src):
-            todo.append([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj])
+            todo.append([HIPCC] + FLAGS + extra + more + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

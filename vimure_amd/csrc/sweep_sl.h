@@ -38,9 +38,21 @@ struct SlArgs {
   int do_hist;   // 1: accumulate the statistics H; 2: count mode (vmr_create): every tie is category 1, slot 1 gets sum x
   int yt, hc;    // levels (mirror counts 0..) of F / of H held in LDS
   int sum_a;     // also sum the (new) rho over the listed reporters of the partial mask rows into slotA
+  // The nu update inside the pass (model.py:820-830): nu_shp - alpha = sum x rho_k w2_k is a linear functional of the
+  // statistics H the pass holds, so every workgroup adds its share to nu_acc[0] and the grid's last one (ticket nu_acc[1])
+  // finishes nu -- no finalize launch on plain sweeps.  nu_acc[2 + l] = sum_{y,m} w2_0 C[l][y][m], the part that comes from
+  // the constant C (H_0 = C - sum_{k>0} H_k), left there by k_fin_gamma.  null: the pass does not touch nu.
+  double* nu_acc; double* elbo_dev; int commit_nu;
 };
 
 struct SlShape { int tpb, yt, hc; size_t smem; };
+
+// Register budget of a variant: the per-tie state grows with K (log prior, sums, rho, table rows: ~14 K registers) and the
+// ELBO variants carry the logarithms' on top, so the kernels are compiled for fewer, fatter waves as K grows -- no variant
+// spills (profiles/r03_kernel_resources.md).  Largest workgroup / waves per SIMD the kernel<K, ., ELBO, .> is compiled for:
+// (allfull: every mask row is all ones -- the variants without the mask code need a few registers fewer)
+constexpr int sl_tpb_max(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 512 : 256) : ((K <= 2 && allfull) ? 1024 : (K <= 4 ? 768 : 512)); }
+constexpr int sl_wpe(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 2 : 1) : ((K <= 2 && allfull) ? 4 : (K <= 4 ? 3 : 2)); }
 
 // LDS bytes of one workgroup of the sweep kernel
 static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {

@@ -23,10 +23,9 @@
 #ifndef VMR_K
 #error "compile with -DVMR_K=<number of categories>"
 #endif
-#ifndef SL_WPE
-#define SL_WPE 4   // waves per SIMD the kernel is compiled for
+#ifndef SL_WPE   // experiments: override the waves per SIMD the K = 2 update variants are compiled for
+#define SL_WPE sl_wpe(2, false, true)
 #endif
-#define SL_TPB_MAX 1024
 #define SL_RG 8    // loads in flight over the further rounds of a long step
 
 template <int K>
@@ -38,12 +37,30 @@ struct StepIn {          // what is prefetched for one step
 };
 
 template <int R> struct RC { static constexpr int value = R; };
+// p + off bytes: a wave-uniform pointer plus a 32-bit per-lane offset (the global_load saddr + voffset form: no 64-bit address
+// arithmetic per lane)
+template <class V> __device__ __forceinline__ const V* at_bytes(const V* p, unsigned off) {
+  return reinterpret_cast<const V*>(reinterpret_cast<const char*>(p) + off);
+}
+template <class V> __device__ __forceinline__ V* at_bytes(V* p, unsigned off) {
+  return reinterpret_cast<V*>(reinterpret_cast<char*>(p) + off);
+}
+// 1 / d for d in [1, 1e305): v_rcp_f64 and two Newton steps (the error of the first, 2e-15, squared); the IEEE divide is 11
+// dependent instructions
+__device__ __forceinline__ double rcp_nr2(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return fma(fma(-d, r, 1.0), r, r);
+}
 #define SL_INL __attribute__((always_inline))
-// table rows read back to back: as many as keep the batch within ~32 registers
-template <int K> struct Batch { static constexpr int value = K <= 2 ? 8 : (K <= 4 ? 4 : 2); };
+// table rows read back to back (one LDS latency per batch): as many as keep a batch within 16 registers
+#ifndef SL_BATCH2
+#define SL_BATCH2 8   // (4: 0.191 ms, 8: 0.188 ms per config-3 launch)
+#endif
+template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 : (K <= 4 ? 2 : 1); };
 
 template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
-__global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g) {
+__global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL)) void k_sweep_sl(SlArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
@@ -83,6 +100,7 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   const double eps = g.eps;
   const float rcp_mp = 1.0f / (float)Mp;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
+  double a0_far = 0.0;   // this lane's share of nu_shp - alpha from reports of levels beyond the LDS copy and from deficits
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   const unsigned* Ql = a.Qt ? a.Qt + (size_t)l * T : nullptr;
   const uint64_t* Rl = a.Rb ? a.Rb + (size_t)l * T * g.W : nullptr;
   double* rl = a.rho + (size_t)l * T * K;
+  double* rho_slack = a.rho + (size_t)g.L * T * K;   // 64 rows behind the last layer (vmr_create)
   const double* lpl = a.logpr + (size_t)l * T * K;
   const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
   const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
@@ -112,28 +131,37 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   unsigned rgv = 0;   // lanes 0..2: rs[s2], rs[s2 + 1], sy[s2] of the NEXT step (loaded one step earlier)
   StepIn<K> P;        // the prefetched step
 
-  auto fetch_range = [&](long long st) SL_INL { rgv = lane < 2 ? rsl[st + lane] : (lane == 2 ? syl[st] : 0u); };
-  // loads of one step's per-tie values ...
+  const unsigned lane4 = (unsigned)lane * 4u, laneK8 = (unsigned)lane * (unsigned)(K * 8);
+  const unsigned T32 = (unsigned)T;   // (< 2^31: checked when the lists are built)
+  // (every lane loads: no mask, no branch around a load -- the compiler counts the step's requests exactly)
+  auto fetch_range = [&](long long st) SL_INL {
+    const unsigned ra = rsl[st + (lane < 1 ? 0 : 1)], ry = syl[st];
+    rgv = lane == 2 ? ry : ra;
+  };
+  // loads of one step's per-tie values: a scalar base per step plus a constant per-lane offset, no masks (the arrays carry
+  // 64 rows of slack; positions past the last tie read them and are switched off through `cls`) ...
   auto fetch_tie = [&](StepIn<K>& d, long long st) SL_INL {
-    const size_t pos = (size_t)st * 64 + lane;
-    const bool ok = pos < T;
+    const size_t row0 = (size_t)st * 64;
+    const bool ok = (unsigned)row0 + (unsigned)lane < T32;
     d.qt = 0u; d.tie = 0u;
     if (ALLFULL) d.cls = ok ? 1u : 0u;
     else {
-      d.cls = ok ? (unsigned)cl[pos] : 0u;
-      d.tie = ok ? pl[pos] : 0u;   // (partial mask rows are found by tie)
+      const unsigned c = (unsigned)*at_bytes(cl + row0, (unsigned)lane);
+      d.cls = ok ? c : 0u;
+      d.tie = *at_bytes(pl + row0, lane4);   // (partial mask rows are found by tie)
     }
-    if (ELBO && Ql) d.qt = ok ? Ql[pos] : 0u;
+    if (ELBO && Ql) d.qt = *at_bytes(Ql + row0, lane4);
 #pragma unroll
     for (int k = 0; k < K; ++k) { d.v[k] = 0.0; d.w[k] = 0.0; }
-    if ((UPDATE || ELBO) && ok) load_k<K>(lpl + pos * K, d.v);
-    if (!UPDATE && ok && a.do_hist != 2) load_k<K>(rl + pos * K, d.w);
+    if (UPDATE || ELBO) load_k<K>(at_bytes(lpl + row0 * K, laneK8), d.v);
+    if (!UPDATE && a.do_hist != 2) load_k<K>(at_bytes(static_cast<const double*>(rl) + row0 * K, laneK8), d.w);
   };
   // ... and of its first CNT rounds (rounds it does not have read later steps' slots, unused; in bounds: SL_SLACK)
   auto fetch_ent = [&](StepIn<K>& d, unsigned base, auto cntc) SL_INL {
     constexpr int CNT = decltype(cntc)::value;
+    const unsigned* pe = El + base;
 #pragma unroll
-    for (int j = 0; j < CNT; ++j) d.e[j] = El[(size_t)base + (unsigned)lane + (unsigned)j * 64];
+    for (int j = 0; j < CNT; ++j) d.e[j] = *at_bytes(pe + j * 64, lane4);
   };
 
   if (s < NS) {   // prologue: this wave's first step
@@ -144,6 +172,7 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
     fetch_tie(P, s);
     fetch_ent(P, ea, RC<SL_PF>{});
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step finds nothing of its own outstanding (see the wait in `body`)
   __syncthreads();   // tables
   double Tfull = 0.0;
   for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
@@ -189,6 +218,15 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
     }
     return Tt;
   };
+  // w2_k(m, y) = z2 / (z1 + z2), z1 = G_theta_m G_lambda_k, z2 = G_nu y (model.py:694-696; 0 at y = 0 and where both vanish)
+  const double gnu_cur = a.par[o.sc + SC_G_NU];
+  const double* Gthg = a.par + o.G_th + (size_t)l * Mp;
+  auto w2_at = [&](unsigned ym, int k) SL_INL -> double {
+    unsigned y = (unsigned)((float)ym * rcp_mp);
+    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const double z2 = gnu_cur * (double)y, den = Gthg[ym - y * (unsigned)Mp] * Gla[k] + z2;
+    return (y == 0u || den == 0.0) ? 0.0 : z2 / den;
+  };
   // the K factors of a (y, m) row that may lie beyond the LDS levels
   auto f_row_any = [&](unsigned ym, double (&f)[K]) SL_INL {
     const bool far = ym >= ytm;
@@ -215,8 +253,16 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
 #pragma unroll
         for (int k = 1; k < K; ++k) atomicAdd(&d[k], xr[k]);
         asm volatile("" ::: "memory");
+        if (a.nu_acc) {   // (the LDS levels' share is taken when they are flushed)
+          const double w0 = w2_at(ym, 0);
+#pragma unroll
+          for (int k = 1; k < K; ++k) a0_far += (w2_at(ym, k) - w0) * xr[k];
+        }
       }
-      if (xd != 0.0) atomicAdd(&Hl[(size_t)ym * K], xd);
+      if (xd != 0.0) {
+        atomicAdd(&Hl[(size_t)ym * K], xd);
+        if (a.nu_acc) a0_far -= w2_at(ym, 0) * xd;
+      }
     }
   };
   // sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps, eps alone outside R  (model.py:967-995)
@@ -255,27 +301,36 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   };
   // H += x rho (+ the ELBO's log terms) over NP entries whose rows are all in LDS; an empty slot adds 0
   auto walk2_near = [&](const unsigned* e, auto npc, const double (&r)[K], const double (&er)[K]) SL_INL {
-    constexpr int NP = decltype(npc)::value;
-    double in_[NP > 0 ? NP : 1];
+    constexpr int NP = decltype(npc)::value, LG = 2;   // logarithms side by side (their chains interleave; more would spill)
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const unsigned ym = SL_YM(e[j]);
-      const double dx = (double)SL_X(e[j]);
-      if (a.do_hist) {
+    for (int j0 = 0; j0 < NP; j0 += LG) {
+      double in_[LG];
 #pragma unroll
-        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
+      for (int u = 0; u < LG; ++u) {
+        if (j0 + u < NP) {
+          const unsigned ym = SL_YM(e[j0 + u]);
+          const double dx = (double)SL_X(e[j0 + u]);
+          if (a.do_hist) {
+#pragma unroll
+            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
+          }
+          if (ELBO) in_[u] = elbo_inner(e[j0 + u], er);
+        }
       }
-      if (ELBO) in_[j] = elbo_inner(e[j], er);
-    }
-    if (ELBO) {
+      if (ELBO) {
 #pragma unroll
-      for (int j = 0; j < NP; ++j) e_log += (double)SL_X(e[j]) * log_tab(in_[j], lt);
+        for (int u = 0; u < LG; ++u) if (j0 + u < NP) e_log += (double)SL_X(e[j0 + u]) * log_tab(in_[u], lt);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every group's table reads and chains to the top: spills)
+      }
     }
   };
   // the deficits x (1 - sum_k rho_k) of ties whose rho does not sum to 1 go to slot 0 of H (global; rare)
   auto deficit = [&](unsigned ent, double dfc) SL_INL {
     const unsigned x = SL_X(ent);
-    if (x != 0u && dfc != 0.0) atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);
+    if (x != 0u && dfc != 0.0) {
+      atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);
+      if (a.nu_acc) a0_far -= w2_at(SL_YM(ent), 0) * ((double)x * dfc);
+    }
   };
   auto near1 = [&](unsigned ent, double (&U)[K]) SL_INL {
     const double dx = (double)SL_X(ent);
@@ -304,15 +359,11 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   auto body = [&](auto rct) SL_INL {
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? SL_PF : RCT;   // rounds held in registers
-    const size_t pos = (size_t)s * 64 + lane;
-    const bool act = pos < T;
+    const size_t row0 = (size_t)s * 64;
+    const bool act = (unsigned)row0 + (unsigned)lane < T32;
     const unsigned ea_c = ea;
     const int Rr = RCT < 0 ? R : RCT;
     const bool far = RCT < 0 && ymax >= lim_y;   // (wave-uniform; the straight-line bodies only see near steps)
-    // Everything this step needs was requested a whole step ago: wait for it HERE, before the next step's requests go out.
-    // (Left to itself the compiler waits at the first use, after the new requests -- and where it cannot tell how many
-    // requests are younger than the ones it needs it drains them all: memory latency in every step.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     const StepIn<K> cur = P;
     // the next step: its range was loaded a step ago; its per-tie values and rounds now.  It has at most as many rounds as
     // this one (sorted order), so NP loads cover them; surplus loads read later steps' slots, unused.  After the wave's last
@@ -346,7 +397,7 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
     };
     double r[K], er[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { r[k] = cur.w[k]; er[k] = 0.0; }
+    for (int k = 0; k < K; ++k) { r[k] = act ? cur.w[k] : 0.0; er[k] = 0.0; }   // (positions past the last tie read slack rows)
     if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
@@ -361,6 +412,10 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
       double U[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) U[k] = 0.0;
+#ifdef SL_DEBUG   // timing experiments (results are wrong): VMR_DEBUG bit 16 = no walk 1, 32 = no walk 2, 8 = no H flush
+      if (g.dbg & 16) { if (RCT < 0 && Rr > SL_PF) ring_fill(); }
+      else
+#endif
       if (RCT >= 0) walk1_near(cur.e, RC<NP>{}, U);
       else if (far) {
 #pragma unroll
@@ -398,7 +453,7 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
         const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
         if (__all(safe)) {
           const double e = exp_tab(d, xt);
-          r[0] = 1.0 / (1.0 + e);
+          r[0] = rcp_nr2(1.0 + e);   // (1 + e in [1, e^700]: no scaling needed)
           r[1] = e * r[0];
           done = true;
         }
@@ -431,12 +486,12 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
           irr = __any(dfc != 0.0);
         }
       }
-      if (act) {
-        store_k<K>(rl + pos * K, r);
-        if (ALLFULL || cls == 1u) {
+      // exactly NST store instructions on every path, no mask (the wait at the bottom of the step counts on it): positions
+      // past the last tie write their (finite) values into the slack rows behind the array
+      store_k<K>(act ? at_bytes(rl + row0 * K, laneK8) : at_bytes(rho_slack, laneK8), r);
+      if (act && (ALLFULL || cls == 1u)) {
 #pragma unroll
-          for (int k = 0; k < K; ++k) accF[k] += r[k];
-        }
+        for (int k = 0; k < K; ++k) accF[k] += r[k];
       }
       if (!ALLFULL && a.sum_a) add_lists(tie, act && cls == 2u, r);
     } else if (a.do_hist) {
@@ -458,6 +513,9 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
       for (int k = 0; k < K; ++k) er[k] = exp_tab(r[k], xt);   // exp(rho), model.py:971
     }
     // ---- walk 2: H of the (new) rho, the ELBO's log terms
+#ifdef SL_DEBUG
+    if (g.dbg & 32) {} else
+#endif
     if (a.do_hist || ELBO) {
       if (RCT >= 0) {
         walk2_near(cur.e, RC<NP>{}, r, er);
@@ -481,6 +539,15 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
       e_lin += en - se * Tt;
       if (Ql) e_q += sr * (double)qt;
     }
+    // Everything the NEXT step needs was requested at the top of this one: wait for it HERE, before the next step's own
+    // requests go out.  (Left to itself the compiler waits at the first use, after those requests -- and where it cannot tell
+    // how many requests are younger than the ones it needs it drains them all: memory latency in every step.)  This step's rho
+    // store is younger than the requests and need not have landed: the counter is in order, so "all but the NST youngest"
+    // covers exactly the loads -- every path through a step issues exactly NST store instructions (see there).
+    constexpr int NST = UPDATE ? (K % 2 == 0 ? K / 2 : K) : 0;
+    static_assert(NST <= 8, "vmcnt immediate below");
+    if (RCT >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);   // vmcnt(NST)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                  // (general steps may add global atomics: vmcnt(0))
     // advance
     s = s2; ea = ea2; R = R2; ymax = ym2;
   };
@@ -505,6 +572,9 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
   }
 
   __syncthreads();
+#ifdef SL_DEBUG
+  if (g.dbg & 8) {} else
+#endif
   if (a.do_hist) {   // flush the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
     for (int q = tid; q < nHc; q += nthr) {
       const double v = Hc[q];
@@ -519,6 +589,40 @@ __global__ __launch_bounds__(SL_TPB_MAX, SL_WPE) void k_sweep_sl(SlArgs a, Geo g
     for (int q = tid; q < g.M * K; q += nthr) {
       const double v = As[q];
       if (v != 0.0) atomicAdd(&out[q], v);
+    }
+  }
+  if (a.nu_acc && a.do_hist == 1) {
+    // this workgroup's share of nu_shp - alpha: sum_{y>0,m,k>0} (w2_k - w2_0) H_k over its LDS levels (+ what the general
+    // code collected), then the ticket; the grid's last workgroup finishes nu (model.py:820-830)
+    double a0p = a0_far;
+    for (int q = tid; q < nHc; q += nthr) {
+      const double v = Hc[q];
+      if (v != 0.0) {
+        const int k1 = q / (int)hcm;
+        const unsigned ym = (unsigned)(q - k1 * (int)hcm);
+        a0p += (w2_at(ym, k1 + 1) - w2_at(ym, 0)) * v;
+      }
+    }
+    a0p = block_sum_n(a0p, red);
+    __shared__ int nu_last;
+    if (tid == 0) {
+      atomicAdd(&a.nu_acc[0], a0p);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (performed at the memory side before the ticket is drawn)
+      const double t = atomicAdd(&a.nu_acc[1], 1.0);
+      nu_last = (t == (double)(gridDim.x - 1));
+      if (nu_last) {
+        double tot = atomicAdd(&a.nu_acc[0], 0.0);   // device-scope read of every workgroup's share
+        for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
+        a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
+        a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
+        if (a.commit_nu) {
+          double* sc = const_cast<double*>(a.par) + o.sc;
+          sc[SC_G_NU_STALE] = sc[SC_G_NU];           // what the last cache refresh held (model.py:684)
+          sc[SC_NU_SHP] = sc[SC_A_ETA] + tot;
+          sc[SC_G_NU] = exp(digamma_pos(sc[SC_NU_SHP]) - log(sc[SC_NU_RTE]));
+          sc[SC_E_NU] = sc[SC_NU_SHP] / sc[SC_NU_RTE];
+        }
+      }
     }
   }
   if (UPDATE || (!ELBO && a.do_hist == 1)) {

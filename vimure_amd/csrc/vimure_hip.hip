@@ -1952,7 +1952,8 @@ __device__ __forceinline__ double h_sum(double* Hl0, size_t, size_t idx) {   // 
 }
 __device__ __forceinline__ double h_at(const double* Hl0, size_t, size_t idx) { return Hl0[idx]; }
 
-#define FIN_TPB 1024   // the finalize kernels are latency-bound chains over H: one workgroup per layer, 16 waves
+#define FIN_TPB 1024
+#define FG_G 16   // workgroups per layer of k_fin_gamma: each owns a range of reporters
 __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) {   // result valid in thread 0
   v = wave_sum(v);
   __syncthreads();
@@ -1965,66 +1966,96 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
   return r;
 }
 
-// finalize kernels (one workgroup per layer)
+// finalize kernels
 // ------------------------------------------------------------------------------------------
-// gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718),
-// then phi_rte from the same A with the new E[theta] (model.py:742-749); mutuality off: phi_shp too.
-// Threads take (y, m) items of H (coalesced, all copies in flight at once), then one thread per reporter
-// finishes gamma.  consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for
-// the rho pass that follows.
-// (Finishing the previous sweep here too -- k_fin_rho's fold of the H copies and the nu update, for handles of one layer, so
-// that a small fit's sweep is two dependent launches instead of three -- was built and measured: one workgroup folding the 8
-// copies takes 38-83 us against 2 x 16-25 us for the two kernels.  Not kept.)
-__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, double* slotA, double* slotF,
-                                                       double* lutg, double* Fg, int do_phi, int consume, Geo g) {
-  extern __shared__ double dyn[];   // s1[Mp]: sum_{y,k} w1 H per reporter; gthn[Mp]: the new G_theta
-  double* s1 = dyn;
-  double* gthn = dyn + g.Mp;
+// gamma_shp from H with the current (old) weights (model.py:698-703), gamma_rte from A (model.py:704-718), then phi_rte from
+// the same A with the new E[theta] (model.py:742-749) and phi_shp from H with the new E[log theta] (model.py:731-733, 861-887;
+// mutuality off: from the level-0 sums), the factor table F of the rho pass, the LUT of E[theta].
+// FG_G workgroups per layer, each owning a range of REPORTERS: everything of gamma is local to a reporter, so a workgroup
+// reads the (y, m) items of its own reporters (kept in registers for the second, phi, use when they are few), finishes their
+// gamma and adds its share of the 2 K sums that lambda needs to `fin` with device-scope atomics; the workgroup that draws the
+// layer's last ticket finishes lambda and builds F and the LUT from the theta values the others published (release before
+// the ticket, acquire after it).  One workgroup per layer (rounds 1-2) kept 4 of 256 CUs busy for 25 us per sweep.
+// consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for the rho pass.
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
+                                                       double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
+                                                       int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, Geo g) {
+  extern __shared__ double dyn[];   // s1[mper]: sum_{y,k} w1 H per reporter; gthn[mper]: the new G_theta
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   __shared__ double lla_n[KMAX], gla_n[KMAX];   // the new E[log lambda], G_lambda (for the factor table F)
-  __shared__ double bsum[2 * KMAX], prte_n[KMAX];
+  __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
+  const int l = blockIdx.x / FG_G, gq = blockIdx.x - l * FG_G, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
+  const int mper = (g.M + FG_G - 1) / FG_G, m0 = gq * mper, m1 = min(g.M, m0 + mper), nm = max(0, m1 - m0);
+  double* s1 = dyn;
+  double* gthn = dyn + mper;
+  double* finl = fin + (size_t)l * (2 * KMAX + 2);
   if (tid < K) {
     double fv[NSLOT], f = 0.0;   // all-ones mask rows, summed by the rho pass (zero when the mask kernel handled them)
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) fv[sl] = slotF[((size_t)l * NSLOT + sl) * K + tid];   // loads first, all in flight
 #pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl) {
-      f += fv[sl];
-      if (consume) slotF[((size_t)l * NSLOT + sl) * K + tid] = 0.0;
-    }
+    for (int sl = 0; sl < NSLOT; ++sl) f += fv[sl];
     fk[tid] = f;
     ela_old[tid] = par[o.p_shp + l * K + tid] / par[o.p_rte + l * K + tid];
     gla_old[tid] = par[o.G_la + l * K + tid];
   }
-  for (int m = tid; m < g.Mp; m += FIN_TPB) { s1[m] = 0.0; gthn[m] = 0.0; }
+  for (int m = tid; m < mper; m += FIN_TPB) { s1[m] = 0.0; gthn[m] = 0.0; }
   __syncthreads();
   const double gnu = par[o.sc + SC_G_NU];
   const size_t hcs = (size_t)g.Y * g.Mp * K;
   double* Hl = Hg + (size_t)l * NH * hcs;
-  const int items = g.Y * g.Mp;
-  const bool phi2 = do_phi && g.mut;   // a second pass over H follows (phi_shp with the new E[log theta])
-  double p0[KMAX];
-  for (int k = 0; k < KMAX; ++k) p0[k] = 0.0;
+  const int items = g.Y * nm;                 // (y, m) items of this workgroup's reporters
+  const bool phi2 = do_phi && g.mut;          // a second use of H follows (phi_shp with the new E[log theta])
+  const bool cached = items <= FIN_TPB;       // one item per thread: its K values stay in registers for that second use
+  double hv[KMAX], p0[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { hv[k] = 0.0; p0[k] = 0.0; }
+  // One (y, m) item: its K values summed over the nh copies the workgroups of the pass added into (all loads in flight at
+  // once).  Report lists (Cl != null) accumulate categories 1..K-1 and, in slot 0, the deficit of irregular ties:
+  // H_0 = C - deficit - sum_{k>0} H_k with C[y][m] = sum x a constant of the data.  zero: leave the copies zeroed.
+  const double* Cl = Cg ? Cg + (size_t)l * g.Y * g.Mp : nullptr;
+  auto item = [&](int y, int m, double (&h_)[KMAX], bool zero) {
+    const size_t base = ((size_t)y * g.Mp + m) * K;
+    double rest = 0.0;
+#pragma unroll
+    for (int k = KMAX - 1; k >= 0; --k) {
+      if (k < K) {
+        double v[NH], t = 0.0;
+#pragma unroll
+        for (int c = 0; c < NH; ++c) v[c] = c < nh ? Hl[(size_t)c * hcs + base + k] : 0.0;   // loads first, all in flight
+#pragma unroll
+        for (int c = 0; c < NH; ++c) {
+          t += v[c];
+          if (zero && c < nh) Hl[(size_t)c * hcs + base + k] = 0.0;
+        }
+        if (k > 0) rest += t;
+        else if (Cl && nh > 1) t = Cl[(size_t)y * g.Mp + m] - t - rest;   // (a folded H holds H_0 itself)
+        h_[k] = t;
+      }
+    }
+  };
   for (int it = tid; it < items; it += FIN_TPB) {
-    const int y = it / g.Mp, m = it - y * g.Mp;
-    if (m >= g.M) continue;
+    const int y = it / nm, m = m0 + (it - y * nm);
     const double gth = par[o.G_th + (size_t)l * g.Mp + m];   // still the old value
     double acc = 0.0;
-    for (int k = 0; k < K; ++k) {
-      const size_t idx = (size_t)it * K + k;
-      const double hv = (consume && !phi2) ? h_sum<true>(Hl, hcs, idx) : h_sum<false>(Hl, hcs, idx);
-      acc += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * hv;
-      if (y == 0) p0[k] += hv;
+    item(y, m, hv, consume && (!phi2 || cached));
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        acc += (g.mut ? w1_of(gth * gla_old[k], gnu * (double)y) : 1.0) * hv[k];
+        if (y == 0) p0[k] += hv[k];
+      }
     }
-    if (acc != 0.0) atomicAdd(&s1[m], acc);
+    if (acc != 0.0) atomicAdd(&s1[m - m0], acc);
   }
   __syncthreads();
   double pr[KMAX];
+#pragma unroll
   for (int k = 0; k < KMAX; ++k) pr[k] = 0.0;
-  for (int m = tid; m < g.M; m += FIN_TPB) {
+  for (int mi = tid; mi < nm; mi += FIN_TPB) {
+    const int m = m0 + mi;
     const size_t q = (size_t)l * g.Mp + m;
     double A[KMAX], rte = 0.0;
     const double pa_th = par[o.a_th + q], pb_th = par[o.b_th + q];
@@ -2041,77 +2072,93 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
       A[k] = ak;
       rte += ela_old[k] * ak;
     }
-    double shp = pa_th + s1[m];
+    double shp = pa_th + s1[mi];
     rte = pb_th + rte;
     par[o.g_shp + q] = shp; par[o.g_rte + q] = rte;
     double e = shp / rte, lg = digamma_pos(shp) - log(rte);
     const double gn = exp(lg);
     par[o.E_th + q] = e; par[o.l_th + q] = lg; par[o.G_th + q] = gn;
-    gthn[m] = gn;
+    gthn[mi] = gn;
     for (int k = 0; k < K; ++k) pr[k] += e * A[k];
   }
-  // the K sums first, then one thread per category finishes its lambda_k (digamma, log, exp and the parameter loads of the K
-  // categories side by side instead of one after the other in thread 0)
-  for (int k = 0; k < K; ++k) {
-    double v = block_sum_fin(pr[k], red);
-    double ps = g.mut ? 0.0 : block_sum_fin(p0[k], red);   // mutuality off: phi_shp = alpha + sum x rho_k (model.py:861-887)
-    if (tid == 0) { bsum[k] = v; bsum[KMAX + k] = ps; }
-  }
   __syncthreads();
-  if (tid < K) {
-    const int k = tid;
-    double rte = par[o.b_la + l * K + k] + bsum[k];
-    if (g.mut) {
-      par[o.p_rte_pend + l * K + k] = rte;
-      prte_n[k] = rte;
-    } else {
-      double shp = par[o.a_la + l * K + k] + bsum[KMAX + k];
-      par[o.p_shp + l * K + k] = shp; par[o.p_rte + l * K + k] = rte;
-      double lg = digamma_pos(shp) - log(rte);
-      par[o.E_la + l * K + k] = shp / rte; par[o.l_la + l * K + k] = lg; par[o.G_la + l * K + k] = exp(lg);
-      lla_n[k] = lg; gla_n[k] = exp(lg);
-    }
-  }
-  // (fused sweep) phi right away: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887),
-  // phi_rte as just computed; then the nibble LUT of the new E[theta] for the rho pass
-  __syncthreads();
+  // phi_shp's share of this workgroup: H with the NEW E[log theta] of its reporters (model.py:731-733, 861-887)
+  double ps[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
   if (phi2) {
-    double ps[KMAX];
-    for (int k = 0; k < KMAX; ++k) ps[k] = 0.0;
-    for (int it = tid; it < items; it += FIN_TPB) {
-      const int y = it / g.Mp, m = it - y * g.Mp;
-      if (m >= g.M) continue;
-      const double gth = gthn[m];
-      for (int k = 0; k < K; ++k) {
-        const size_t idx = (size_t)it * K + k;
-        const double hv = consume ? h_sum<true>(Hl, hcs, idx) : h_sum<false>(Hl, hcs, idx);
-        ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * hv;
+    if (cached) {
+      if (tid < items) {
+        const int y = tid / nm, mi = tid - y * nm;
+        const double gth = gthn[mi];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) ps[k] = w1_of(gth * gla_old[k], gnu * (double)y) * hv[k];
+      }
+    } else {
+      for (int it = tid; it < items; it += FIN_TPB) {
+        const int y = it / nm, mi = it - y * nm;
+        const double gth = gthn[mi];
+        double h2[KMAX];
+        item(y, m0 + mi, h2, consume != 0);
+        for (int k = 0; k < K; ++k) ps[k] += w1_of(gth * gla_old[k], gnu * (double)y) * h2[k];
       }
     }
-    for (int k = 0; k < K; ++k) {
-      double v = block_sum_fin(ps[k], red);
-      if (tid == 0) bsum[k] = v;
-    }
-    __syncthreads();
-    if (tid < K) {
-      const int k = tid, q = l * K + k;
-      double shp = par[o.a_la + q] + bsum[k], rte = prte_n[k];   // (phi_rte as computed above, also in p_rte_pend)
+  } else if (!g.mut) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) ps[k] = p0[k];   // mutuality off: phi_shp = alpha + sum x rho_k
+  }
+  // this workgroup's shares of the 2 K sums, then its ticket
+  for (int k = 0; k < K; ++k) {
+    const double v = block_sum_fin(pr[k], red);
+    const double w = block_sum_fin(ps[k], red);
+    if (tid == 0) { atomicAdd(&finl[k], v); atomicAdd(&finl[KMAX + k], w); }
+  }
+  // publish this workgroup's theta values (every storing wave drained, then one agent-scope release) before the ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const double t = atomicAdd(&finl[2 * KMAX], 1.0);
+    last = (t == (double)(FG_G - 1));
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (!last) return;
+  // ---- the layer's last workgroup: lambda, the factor table F, the LUT -------------------------------------------------
+  if (tid < K) {
+    const int k = tid, q = l * K + k;
+    const double sr = atomicAdd(&finl[k], 0.0), ss = atomicAdd(&finl[KMAX + k], 0.0);   // (device-scope reads)
+    const double rte = par[o.b_la + q] + sr;
+    if (g.mut && !do_phi) {
+      par[o.p_rte_pend + q] = rte;   // the PHI sub-step commits (k_fin_phi)
+    } else {
+      const double shp = par[o.a_la + q] + ss;
       par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
-      double lg = digamma_pos(shp) - log(rte);
+      if (g.mut) par[o.p_rte_pend + q] = rte;
+      const double lg = digamma_pos(shp) - log(rte);
       par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
       lla_n[k] = lg; gla_n[k] = exp(lg);
     }
   }
+  __syncthreads();
+  if (tid == 0) { for (int k = 0; k < 2 * KMAX + 1; ++k) finl[k] = 0.0; }   // scratch ready for the next sweep
+  if (consume && tid < K) {
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) slotF[((size_t)l * NSLOT + sl) * K + tid] = 0.0;   // (every workgroup of the layer has read it)
+  }
   // (fused sweep, report lists) the factor table F of the rho pass from the new theta, lambda and the current nu
   if (do_phi && Fg) {
-    __syncthreads();   // (also makes this workgroup's stores of the new E[log theta] visible to all its threads)
-    double* Fl = Fg + (size_t)l * items * K;
+    const int all = g.Y * g.Mp;
+    double* Fl = Fg + (size_t)l * all * K;
     const double* lthn = par + o.l_th + (size_t)l * g.Mp;
-    for (int it = tid; it < items; it += FIN_TPB) {
+    const double* gthg = par + o.G_th + (size_t)l * g.Mp;
+    for (int it = tid; it < all; it += FIN_TPB) {
       const int y = it / g.Mp, m = it - y * g.Mp;
-      const double lt = (m < g.M) ? lthn[m] : 0.0;
+      const double lt = (m < g.M) ? lthn[m] : 0.0, gt = (m < g.M) ? gthg[m] : 0.0;
       for (int k = 0; k < K; ++k)
-        Fl[(size_t)it * K + k] = (m < g.M) ? f_entry(g.mut, lt, gthn[m], lla_n[k], gla_n[k], gnu, y) : 0.0;
+        Fl[(size_t)it * K + k] = (m < g.M) ? f_entry(g.mut, lt, gt, lla_n[k], gla_n[k], gnu, y) : 0.0;
     }
   }
   const double* Eth = par + o.E_th + (size_t)l * g.Mp;
@@ -2123,6 +2170,21 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
       if (((e >> u) & 1) && m < g.Mp) v += Eth[m];
     }
     lutg[(size_t)l * g.W * 256 + q] = v;
+  }
+  // (fused sweep, sorted lists) the constant part of the nu update the rho pass finishes itself (SlArgs::nu_acc):
+  // sum_{y>0,m} w2_0(m, y) C[l][y][m] with the new theta, lambda and the current nu
+  if (nu_acc && do_phi && g.mut && Cl) {
+    const double* gthg = par + o.G_th + (size_t)l * g.Mp;
+    double c0 = 0.0;
+    for (int it = tid; it < g.Y * g.Mp; it += FIN_TPB) {
+      const int y = it / g.Mp, m = it - y * g.Mp;
+      if (y > 0 && m < g.M) {
+        const double z2 = gnu * (double)y, den = gthg[m] * gla_n[0] + z2;
+        if (den != 0.0) c0 += (z2 / den) * Cl[it];
+      }
+    }
+    c0 = block_sum_fin(c0, red);
+    if (tid == 0) nu_acc[2 + l] = c0;
   }
 }
 
@@ -2167,14 +2229,14 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 // last ticket (fin[2]) finishes the scalars and clears the scratch.
 #define FR_G 16   // workgroups per layer of k_fin_rho
 __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
-                                                 double* fin, int do_nu, int do_elbo, int fold, Geo g) {
+                                                 double* fin, int do_nu, int do_elbo, int fold, int skip_nu /* the pass finished nu itself */, Geo g) {
   __shared__ double red[8];
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
   const int l = blockIdx.x / FR_G, gs = blockIdx.x - l * FR_G;
   double a0 = 0.0, gt = 0.0;
-  if (g.mut || fold) {   // threads take (y, m) items of H; fold: the NH copies are summed into copy 0 on the way
+  if (!skip_nu && (g.mut || fold)) {   // threads take (y, m) items of H; fold: the NH copies are summed into copy 0 on the way
     const double gnu = sc[SC_G_NU];
     const size_t hcs = (size_t)g.Y * g.Mp * g.K;
     double* Hl = Hg + (size_t)l * NH * hcs;
@@ -2209,7 +2271,9 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const 
   if (threadIdx.x == 0) {
     atomicAdd(&fin[0], a0);
     atomicAdd(&fin[1], gt);
-    __threadfence();
+    // the two adds are performed at the memory side before the ticket is drawn: they stay counted until they are (a full
+    // __threadfence() -- L2 write-back and invalidate, ~3.5 us -- orders plain stores, of which the ticket publishes none)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double t = atomicAdd(&fin[2], 1.0);
     last = (t == (double)(gridDim.x - 1));
   }
@@ -2238,7 +2302,7 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const 
       elbo_out[0] = e;
     }
     // raw pieces for fits whose layers are spread over several handles (vmr_sweep_local)
-    elbo_out[1] = a0;             // sum x w2 rho over the local layers (nu_shp - alpha_eta)
+    if (!skip_nu) elbo_out[1] = a0;   // sum x w2 rho over the local layers (nu_shp - alpha_eta)
     elbo_out[2] = a1 + a2 + gt;   // local ELBO terms that do not involve nu
     elbo_out[3] = a3;             // local sum_t (sum_k rho) Q_t, enters the ELBO as -E[nu] * (.)
   }
@@ -2372,7 +2436,7 @@ static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 // Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
-  SlShape s{h->sp_tpb, update ? g.yt : 0, hist ? g.hc : 0, 0};
+  SlShape s{std::min(h->sp_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0)), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -2380,7 +2444,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, h->Fg, 1, do_hist, sh.yt, sh.hc, sum_a};
+                h->lutg, h->Hg, h->slotF, h->slotA, h->Fg, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0};
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -2417,13 +2481,13 @@ static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
 
 
 // k_fin_rho: nu and/or the ELBO; folds the NH copies of H into copy 0 on its way when they are not folded yet
-static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo) {
+static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo, int skip_nu = 0) {
   const Geo& g = h->g;
-  const int fold = (h->h_valid && !h->h_reduced) ? 1 : 0;
+  const int fold = (!skip_nu && h->h_valid && !h->h_reduced) ? 1 : 0;
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->Cg, h->slotR, h->elbo_dev,
-                       h->elbo_dev + 4, do_nu, do_elbo, fold, g);
+                       h->elbo_dev + 4, do_nu, do_elbo, fold, skip_nu, g);
   }
   HIPCHK(h, hipGetLastError());
   if (fold) h->h_reduced = true;
@@ -2458,7 +2522,8 @@ static long long sp_grid_cap(const Geo& g, int tpb) {
 }
 
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
-static int launch_hist(vmr_ctx* h) {
+// nu: -1 = the pass leaves nu alone; 0 = it leaves the raw sum in elbo_dev[1]; 1 = it also commits nu (sorted lists, see SlArgs::nu_acc)
+static int launch_hist(vmr_ctx* h, int nu = -1) {
   const Geo& g = h->g;
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
@@ -2469,6 +2534,7 @@ static int launch_hist(vmr_ctx* h) {
     if (h->sl) {
       const SlShape shs = sl_shape(h, false, false, true);
       SlArgs as = sl_args(h, shs, 1, g.ml);
+      if (nu >= 0 && g.mut) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = nu; }
       int rcs = sl_launch(h, 3, shs, as);
       if (rcs) return rcs;
       HIPCHK(h, hipGetLastError());
@@ -2552,18 +2618,16 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     int rc = launch_hist(h);
     if (rc) return rc;
   }
-  { int rc = ensure_h_folded(h); if (rc) return rc; }
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
-    // fused sweep: this is the last reader of H and slotF before the rho pass rebuilds them, so it leaves them zeroed
+    // fused sweep: this is the last reader of H and slotF before the rho pass rebuilds them, so it leaves them zeroed.  It
+    // sums the NH copies the workgroups of the pass added into on its way (nh = 1 when something folded them already).
     const int consume = (with_phi && !g.two_pass) ? 1 : 0;
-    const size_t fsm = (size_t)2 * g.Mp * 8;
-    if (fsm > 48 * 1024 && !h->fin_attr) {
-      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fin_gamma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm));
-      h->fin_attr = true;
-    }
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->lutg,
-                       h->sparse ? h->Fg : nullptr, with_phi ? 1 : 0, consume, g);
+    const int nh = h->h_reduced ? 1 : NH;
+    const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
+    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
+                       h->slotF, h->lutg, h->sparse ? h->Fg : nullptr, h->fin_g, (h->sparse && h->sl) ? h->nu_acc : nullptr, nh,
+                       with_phi ? 1 : 0, consume, g);
     h->ftab_valid = h->sparse && with_phi;
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
     if (consume) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
@@ -2586,7 +2650,8 @@ static int launch_phi(vmr_ctx* h) {
 }
 
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
-static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
+// raw_nu: leave the raw nu sum in elbo_dev[1] although nu is not committed (vmr_sweep_local)
+static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false) {
   const Geo& g = h->g;
   RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
@@ -2605,6 +2670,8 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     }
     h->ftab_valid = false;   // the nu update that follows changes the weights
   }
+  // sorted lists with mutuality: the pass that builds H finishes nu itself -- no finalize launch on plain sweeps
+  const bool nu_in_pass = h->sparse && h->sl && g.mut && mode != 2 && (commit_nu || raw_nu);
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
@@ -2614,6 +2681,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     if (h->sl) {
       const SlShape shs = sl_shape(h, mode != 2, mode != 0, do_hist != 0);
       SlArgs as = sl_args(h, shs, do_hist, sum_a);
+      if (nu_in_pass && do_hist) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = commit_nu ? 1 : 0; }
       if ((rc = sl_launch(h, mode, shs, as))) return rc;
     } else {
     const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
@@ -2646,10 +2714,13 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu) {
     h->f_valid = g.fuse_full != 0;
     h->h_valid = !g.two_pass;
     if (!g.two_pass) h->h_reduced = false;
-    if (g.two_pass && (rc = launch_hist(h))) return rc;   // wide reporter dimension: second pass rebuilds H
+    if (g.two_pass && (rc = launch_hist(h, nu_in_pass ? (commit_nu ? 1 : 0) : -1))) return rc;   // wide reporter dimension: second pass rebuilds H
   }
   HIPCHK(h, hipGetLastError());
-  if (mode != 0 || commit_nu) {
+  if (nu_in_pass || (h->sparse && h->sl && mode != 2 && !g.mut)) {
+    // nu is done (or there is none): the finalize kernel only assembles an ELBO
+    if (mode != 0 && (rc = launch_fin_rho(h, 0, 1, 1))) return rc;
+  } else if (mode != 0 || commit_nu) {
     if ((rc = launch_fin_rho(h, (mode != 2 && commit_nu) ? 1 : 0, mode != 0 ? 1 : 0))) return rc;
   }
   return VMR_OK;
@@ -2744,8 +2815,11 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
 static int create_state(vmr_ctx* h, unsigned* xm_out) {
   Geo& g = h->g;
   const size_t rows = (size_t)g.L * g.N * g.N;
-  CK(hipMalloc(&h->rho, rows * g.K * 8));
-  CK(hipMalloc(&h->logpr, rows * g.K * 8));
+  // (64 rows of zeroed slack: the sweep over the sorted lists reads whole 64-tie steps without masks)
+  CK(hipMalloc(&h->rho, (rows + 64) * g.K * 8));
+  CK(hipMalloc(&h->logpr, (rows + 64) * g.K * 8));
+  CK(hipMemsetAsync(h->rho + rows * g.K, 0, (size_t)64 * g.K * 8, h->stream));
+  CK(hipMemsetAsync(h->logpr + rows * g.K, 0, (size_t)64 * g.K * 8, h->stream));
   ParOff o = par_off(g.L, g.Mp, g.K);
   h->par_doubles = o.total;
   CK(hipMalloc(&h->par, o.total * 8));
@@ -2887,11 +2961,13 @@ static int sl_finish(vmr_ctx* h) {
   const size_t rows = (size_t)g.L * g.N * g.N;
   int rc = VMR_OK;
   if (!h->all_full) {
-    CK(hipMalloc(&h->cls_p, rows));
+    CK(hipMalloc(&h->cls_p, rows + 64));   // (64 entries of slack, as rho)
+    CK(hipMemsetAsync(h->cls_p + rows, 0, 64, h->stream));
     if ((rc = sl_permute_u8(h, h->rcls, h->cls_p))) return rc;
   }
   if (g.mut && h->Qt) {
-    CK(hipMalloc(&h->Qt_p, rows * 4));
+    CK(hipMalloc(&h->Qt_p, (rows + 64) * 4));
+    CK(hipMemsetAsync(h->Qt_p + rows, 0, 64 * 4, h->stream));
     if ((rc = sl_permute_u32(h, h->Qt, h->Qt_p))) return rc;
     CK(hipStreamSynchronize(h->stream));
     CK(hipFree(h->Qt)); h->Qt = nullptr;   // (only the sweeps read it)
@@ -2917,16 +2993,18 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     // statistics pass rebuilds H (two passes over the entries).
     auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
     const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 12)));
+    const int cap = sl_tpb_max(K, false, h->all_full != 0), wcu = 4 * sl_wpe(K, false, h->all_full != 0);   // the update variant's workgroup / waves per CU (registers)
     auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {
       const size_t b = sl_smem(g, yt, hc, upd, false, hist);
-      if (b > SP_LDS_MAX) return 0;
-      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), 32 / nw);
+      if (b > SP_LDS_MAX || tpb > cap) return 0;
+      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), wcu / nw);
       return wgs * nw;
     };
     auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {
+      min_waves = std::min(min_waves, wcu);
       for (int lv = want; lv >= 1; --lv) {
         int bw = 0, bt = 256;
-        for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
+        for (int tpb : {1024, 768, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
         if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
       }
       return false;
@@ -3011,6 +3089,10 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   CK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
   CK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
   CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
+  CK(hipMalloc(&h->nu_acc, (size_t)(2 + L) * 8));   // the nu update inside the pass (SlArgs::nu_acc)
+  CK(hipMemsetAsync(h->nu_acc, 0, (size_t)(2 + L) * 8, h->stream));
+  CK(hipMalloc(&h->fin_g, (size_t)L * (2 * KMAX + 2) * 8));   // k_fin_gamma: per layer 2 K sums and a ticket
+  CK(hipMemsetAsync(h->fin_g, 0, (size_t)L * (2 * KMAX + 2) * 8, h->stream));
   CK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
   CK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
   if (h->sparse) {
@@ -3441,7 +3523,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3672,9 +3754,9 @@ int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;
-  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;   // rho updated, nu NOT committed
-  if (!want_elbo) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
-    if ((rc = launch_fin_rho(h, 0, 0))) return rc;
+  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false, true))) return rc;   // rho updated, nu NOT committed
+  if (!want_elbo && !(h->sparse && h->sl)) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
+    if ((rc = launch_fin_rho(h, 0, 0))) return rc;   // (sorted lists: the pass left the raw nu sum itself)
   }
   double v[4];
   HIPCHK(h, hipMemcpyAsync(v, h->elbo_dev, 32, hipMemcpyDeviceToHost, h->stream));
@@ -3700,8 +3782,8 @@ int vmr_sweep_local_dev(vmr_handle h, int want_elbo, double* out3_dev) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;
-  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false))) return rc;
-  if (!want_elbo && (rc = launch_fin_rho(h, 0, 0))) return rc;
+  if ((rc = launch_rho(h, want_elbo ? 1 : 0, false, true))) return rc;
+  if (!want_elbo && !(h->sparse && h->sl) && (rc = launch_fin_rho(h, 0, 0))) return rc;
   HIPCHK(h, hipMemcpyAsync(out3_dev, h->elbo_dev + 1, 24, hipMemcpyDeviceToDevice, h->stream));
   return VMR_OK;
 }
@@ -3881,6 +3963,9 @@ int vmr_profile(vmr_handle h, int enable) {
   int rc = prof_collect(h);
   if (rc) return rc;
   h->prof = enable != 0;
+  // enable = 2: only the passes over the data (the roofline kernels); the small finalize kernels run unbracketed -- two event
+  // records per launch are ~4 us on the stream, 9 % of a config-3 sweep when every kernel carries them
+  h->prof_mask = enable == 2 ? ((1u << VMR_KERNEL_GAMMA_COUNTS) | (1u << VMR_KERNEL_RHO) | (1u << VMR_KERNEL_ELBO) | (1u << VMR_KERNEL_RHO_ELBO)) : ~0u;
   if (enable) { memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n); }
   return VMR_OK;
 }

@@ -131,6 +131,8 @@ struct vmr_ctx {
   unsigned long long n_partial = 0;
   unsigned* xmax = nullptr;
   double* elbo_dev = nullptr;  // [0] elbo
+  double* fin_g = nullptr;     // [L][2 KMAX + 2] scratch of k_fin_gamma
+  double* nu_acc = nullptr;    // [2 + L] the nu update inside the sweep (SlArgs::nu_acc)
   double* lutg = nullptr;      // wide masks (W > 4): the nibble LUT of E[theta] lives in global memory [L][W*256]
   bool have_priors = false, have_state = false;
   bool serial = false;
@@ -138,6 +140,7 @@ struct vmr_ctx {
   std::vector<std::pair<const void*, int>> occ;   // kernel -> resident workgroups per CU   // a rho sub-step left an unconsumed nu partial in slotR
   // profiling
   bool prof = false;
+  unsigned prof_mask = ~0u;    // kernel classes whose launches are bracketed by events (vmr_profile)
   struct Ev { int cls; hipEvent_t a, b; };
   std::vector<Ev> evs;
   double prof_ms[VMR_KERNEL_COUNT];
@@ -384,10 +387,10 @@ static inline int fail(vmr_handle h, int code, const char* msg) {
 struct Prof {
   vmr_ctx* h; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
   Prof(vmr_ctx* h_, int c, hipStream_t st_ = nullptr) : h(h_), cls(c), st(st_ ? st_ : h_->stream) {
-    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    if (h->prof && ((h->prof_mask >> cls) & 1u)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
   }
   ~Prof() {
-    if (h->prof) { (void)hipEventRecord(b, st); h->evs.push_back({cls, a, b}); }
+    if (a) { (void)hipEventRecord(b, st); h->evs.push_back({cls, a, b}); }
   }
 };
 

@@ -337,6 +337,7 @@ class CaviEngine:
 
     # -- measurement
     def profile(self, enable=True):
+        """HIP events around the engine's kernels; enable=2: only around the passes over the data (not the finalize kernels)."""
         self._check(self.lib.vmr_profile(self._h, int(enable)))
 
     def profile_read(self):
