@@ -17,11 +17,11 @@ for p in ("p1", "p2", "p3"):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
         seen = set()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:52]
+            k = r["Kernel_Name"][:64]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (k, r["Dispatch_Id"])
             if key not in seen: seen.add(key); n[k] += 1
         for k in acc:
-            if "k_rho_sp" in k:
+            if "k_rho_sp" in k or "k_sweep_sl" in k:
                 print(p, k, n[k], {c: round(v / n[k]) for c, v in acc[k].items()})
 PY

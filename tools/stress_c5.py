@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--parity", action="store_true")
+    ap.add_argument("--burn", type=int, default=0, help="sweeps before the timed ones (the first sweeps of this regime leave many all-zero rho rows)")
+    ap.add_argument("--zero-rows", action="store_true", help="report the fraction of ties whose rho is all zero after the timed sweeps")
     a = ap.parse_args()
     import torch
     from vimure_amd import CaviEngine
@@ -42,6 +44,8 @@ def main():
         e1 = eng.step(1, want_elbo=True)
     except ValueError:   # (timing experiments with VMR_DEBUG give wrong numbers, possibly NaN)
         e1 = float("nan")
+    if a.burn:
+        eng.step(a.burn)
     eng.profile(True)
     t0 = time.perf_counter()
     eng.step(a.steps)
@@ -57,6 +61,11 @@ def main():
            "kernels": {k: {"avg_ms": v["ms"] / max(1, v["launches"]),
                            "TBps": v["bytes_per_launch"] / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e12 if v["ms"] > 0 and v["bytes_per_launch"] else None}
                        for k, v in prof.items() if v["launches"]}}
+    if a.zero_rows:
+        rho = eng.get_state(rho=True)["rho"]
+        out["zero_rho_rows"] = float((rho == 0.0).all(axis=-1).mean())
+        out["rho_row_sum_min"] = float(rho.sum(axis=-1).min())
+        del rho
     if a.parity:
         # the coordinate-list oracle: no dense 64 GB tensor on the host
         from oracle import cavi_coo

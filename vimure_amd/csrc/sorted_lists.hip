@@ -26,9 +26,17 @@ __global__ __launch_bounds__(256) void k_sl_place(const unsigned* __restrict__ p
     const bool ok = t != 0xffffffffu;
     const unsigned r0 = ok ? rpl[t] : 0u, n = ok ? rpl[t + 1] - r0 : 0u;
     const unsigned ea = rsl[s], R = (rsl[s + 1] - ea) >> 6;
+    // A tie's reports arrive in reporter order.  Left like that, round r would hold the r-th smallest reporter of all 64
+    // ties -- a narrow band of table rows, several lanes on the SAME row: the LDS float atomics of walk 2 then serialise
+    // (config-5 layer: 77 cycles per wave-instruction against ~25).  Every tie's list is therefore rotated by a per-tie
+    // pseudo-random offset, which spreads a round over the whole reporter range.
+    unsigned rot = 0;
+    if (n > 1) { unsigned hsh = t * 0x9E3779B1u; hsh ^= hsh >> 15; hsh *= 0x85EBCA77u; hsh ^= hsh >> 13; rot = hsh % n; }
     unsigned ymx = 0;
     for (unsigned r = 0; r < R; ++r) {
-      const unsigned e = n > r ? Ein[(size_t)r0 + r] : 0u;
+      unsigned q = r + rot;
+      if (q >= n) q -= n;
+      const unsigned e = n > r ? Ein[(size_t)r0 + q] : 0u;
       Eout[(size_t)ea + r * 64 + lane] = e;
       ymx = max(ymx, SL_YM(e) / (unsigned)Mp);
     }

@@ -23,7 +23,14 @@
 #define SL_X(e) ((e) >> 21)
 #define SL_XMAX 2047u          // largest count an entry holds
 #define SL_YM_ROWS (1u << 20)  // (max count + 1) * Mp must not exceed this
-#define SL_PF 8                // rounds of a step that are prefetched one step ahead (registers)
+#define SL_PF 8                // steps of up to this many rounds run in straight-line code compiled for their round count
+// rounds of a step that are prefetched one step ahead (registers) = the depth of the ring that streams the further rounds of a
+// longer step: what a wave keeps in flight.  K >= 3 has the register budget (sl_wpe) for 16: a config-5 layer has 19 reports
+// per tie, and with 8 its steps ran at the latency of 8 x 256 B per wave (N = 3000 layer: rho pass 0.87 ms).
+#ifndef SL_PFW
+#define SL_PFW 16
+#endif
+constexpr int sl_pf(int K) { return K <= 2 ? SL_PF : SL_PFW; }
 #define SL_SLACK (64 * 64)     // entry slots past the last one that prefetches may read (never use)
 
 struct SlArgs {
@@ -33,7 +40,7 @@ struct SlArgs {
   const unsigned* Qt;    // [L][T] by position: sum_m R[t,m] X[mirror(t),m]
   const uint64_t* Rb; const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask rows, by TIE
   double* rho; const double* logpr;   // [L][T][K] by position
-  const double* par; double* slotR; const double* lutg; double* Hg; double* slotF; double* slotA; const double* Fg;
+  const double* par; double* slotR; const double* lutg; double* Hg; double* slotF; double* slotA;
   int Gl;        // workgroups per layer
   int do_hist;   // 1: accumulate the statistics H; 2: count mode (vmr_create): every tie is category 1, slot 1 gets sum x
   int yt, hc;    // levels (mirror counts 0..) of F / of H held in LDS
@@ -41,8 +48,12 @@ struct SlArgs {
   // The nu update inside the pass (model.py:820-830): nu_shp - alpha = sum x rho_k w2_k is a linear functional of the
   // statistics H the pass holds, so every workgroup adds its share to nu_acc[0] and the grid's last one (ticket nu_acc[1])
   // finishes nu -- no finalize launch on plain sweeps.  nu_acc[2 + l] = sum_{y,m} w2_0 C[l][y][m], the part that comes from
-  // the constant C (H_0 = C - sum_{k>0} H_k), left there by k_fin_gamma.  null: the pass does not touch nu.
+  // the constant C (H_0 = C - sum_{k>0} H_k), left there by k_fin_gamma; nu_acc[2 + L] != 0: some workgroup sent a deficit to
+  // the global table.  null: the pass does not touch nu.
   double* nu_acc; double* elbo_dev; int commit_nu;
+#ifdef SL_DEBUG
+  unsigned long long* dbg_t;   // [waves][4]: a wave's start, end of prologue, end of step loop, end (100 MHz clock)
+#endif
 };
 
 struct SlShape { int tpb, yt, hc; size_t smem; };
@@ -57,7 +68,7 @@ constexpr int sl_wpe(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 2
 // LDS bytes of one workgroup of the sweep kernel
 static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
-  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) +
+  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (size_t)g.Mp * 8 * (update ? 2 : 1) +
          (size_t)g.W * 8 + 128 + (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
 }
 

@@ -26,14 +26,13 @@
 #ifndef SL_WPE   // experiments: override the waves per SIMD the K = 2 update variants are compiled for
 #define SL_WPE sl_wpe(2, false, true)
 #endif
-#define SL_RG 8    // loads in flight over the further rounds of a long step
 
 template <int K>
 struct StepIn {          // what is prefetched for one step
   double v[K];           // log prior (UPDATE or ELBO)
   double w[K];           // current rho (not UPDATE)
   unsigned cls, qt, tie;
-  unsigned e[SL_PF];
+  unsigned e[sl_pf(K)];
 };
 
 template <int R> struct RC { static constexpr int value = R; };
@@ -57,11 +56,12 @@ __device__ __forceinline__ double rcp_nr2(double d) {
 #ifndef SL_BATCH2
 #define SL_BATCH2 8   // (4: 0.191 ms, 8: 0.188 ms per config-3 launch)
 #endif
-template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 : (K <= 4 ? 2 : 1); };
+template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 : (K <= 4 ? 4 : 2); };
 
 template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
 __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL)) void k_sweep_sl(SlArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int Mp = g.Mp;
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   double* F = reinterpret_cast<double*>(smem + off); off += (size_t)ytm * K * 8;            // [yt][Mp][K]
   const int nHc = (int)hcm * (K - 1);
   double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                // [K-1][hc][Mp]
-  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)Mp * 8 : 0;
+  // per-reporter tables: G_theta (the factor table, the ELBO's inner sums, the nu weights) and E[log theta] (the factor table)
+  double* Gth = reinterpret_cast<double*>(smem + off); off += (size_t)Mp * 8;
+  double* Lth = reinterpret_cast<double*>(smem + off); off += UPDATE ? (size_t)Mp * 8 : 0;
   double* As = reinterpret_cast<double*>(smem + off); off += a.sum_a ? (size_t)Mp * K * 8 : 0;   // [Mp][K]
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
@@ -79,28 +81,33 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+#ifdef SL_DEBUG
+  unsigned long long* dbt = a.dbg_t ? a.dbg_t + ((size_t)blockIdx.x * nw + wv) * 4 : nullptr;
+  if (dbt && lane == 0) dbt[0] = wall_clock64();
+#endif
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);
   const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
-  const double* Fl = a.Fg + (size_t)l * g.Y * Mp * K;
-  for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
+  for (int m = tid; m < Mp; m += nthr) {
+    Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
+    if (UPDATE) Lth[m] = a.par[o.l_th + (size_t)l * Mp + m];
+  }
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
   if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
   if (UPDATE || ELBO) sp_math_tables(xt, lt, tid, nthr);
-  if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
   const double* lut = a.lutg + (size_t)l * g.W * 256;
   for (int w = tid; w < g.W; w += nthr) {
     double v = 0.0;
     for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
     wsum[w] = v;
   }
-  double Ela[K], Gla[K];
+  double Ela[K], Gla[K], Lla[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; }
+  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; Lla[k] = a.par[o.l_la + l * K + k]; }
   const double eps = g.eps;
   const float rcp_mp = 1.0f / (float)Mp;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
-  double a0_far = 0.0;   // this lane's share of nu_shp - alpha from reports of levels beyond the LDS copy and from deficits
+  bool dflag = false;   // this lane sent a deficit to the global table (tells the grid's last workgroup to look: nu_far)
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
@@ -118,13 +125,27 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
   const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
   const double* Eth = a.par + o.E_th + (size_t)l * Mp;
-  // a step is "far" when one of its reports lies in a level beyond the LDS copies this launch holds
+  // a step is "far" when one of its reports lies in a level beyond the LDS copies this launch holds: it takes the general body,
+  // which decides per group of reports (lim1 / lim2: first level beyond the copies of F / H, none when every level is held)
   const unsigned lim_y = UPDATE ? (a.do_hist ? (unsigned)min(a.yt, a.hc) : (unsigned)a.yt) : (a.do_hist ? (unsigned)a.hc : 0xffffffffu);
+  const unsigned lim1 = (UPDATE && a.yt < g.Y) ? (unsigned)a.yt : 0xffffffffu;
+  const unsigned lim2 = (a.do_hist && a.hc < g.Y) ? (unsigned)a.hc : 0xffffffffu;
 
-  // steps of this wave: s = gw, gw + GW, ...  (waves interleave: neighbouring waves read neighbouring memory, and every wave
-  // sees the whole range of R)
-  const long long GW = (long long)a.Gl * nw, gw = (long long)gb * nw + wv;
-  long long s = gw;
+  // Steps of this workgroup: gb, gb + Gl, gb + 2 Gl, ... -- every workgroup sees the whole range of the sorted order -- handed to
+  // its waves in that order by a ticket counter in LDS: the order is by falling number of rounds, so a wave that drew a long step
+  // draws fewer.  (A fixed share per wave left a few waves with all the longest steps: the ties of BASELINE config 5's 1.9 % true
+  // edges carry 1000 reports against 19 for the rest, and an eighth of the waves ran five times as long as the others.)  The
+  // first two tickets of a wave are fixed -- wv and nw + wv -- so that its first loads go out before the tables are built.
+  const long long Gl_ = a.Gl;
+  unsigned* tick = reinterpret_cast<unsigned*>(smem + off); off += 16;
+  if (tid == 0) *tick = 2u * (unsigned)nw;
+  auto step_of = [&](unsigned t) SL_INL -> long long { return (long long)gb + (long long)t * Gl_; };
+  auto draw = [&]() SL_INL -> long long {   // this wave's next ticket (one LDS atomic by lane 0)
+    unsigned t = 0u;
+    if (lane == 0) t = atomicAdd(tick, 1u);
+    return step_of((unsigned)__builtin_amdgcn_readfirstlane((int)t));
+  };
+  long long s = step_of((unsigned)wv), sn = step_of((unsigned)(nw + wv));   // the current step and the next
   unsigned ea = 0;    // first slot of the current step
   int R = 0;          // its rounds
   unsigned ymax = 0;  // its highest mirror-count level
@@ -168,14 +189,29 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
     ea = rsl[s];
     R = (int)((rsl[s + 1] - ea) >> 6);
     ymax = syl[s];
-    fetch_range(s + GW < NS ? s + GW : s);
+    fetch_range(sn < NS ? sn : s);
     fetch_tie(P, s);
-    fetch_ent(P, ea, RC<SL_PF>{});
+    fetch_ent(P, ea, RC<PFK>{});
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step finds nothing of its own outstanding (see the wait in `body`)
-  __syncthreads();   // tables
+  __syncthreads();   // per-reporter tables
+  // The factor table of the rho update, F[y][m][k] = (E log theta_m + E log lambda_k) w1_k(m, y) (model.py:685-693, 911-921), for
+  // the levels this launch keeps in LDS: a few divides per thread from the per-reporter tables -- no global table, no kernel
+  // that builds one.  Reports of levels beyond take the same formula on the fly (f_far).
+  const double gnu_f = a.par[o.sc + SC_G_NU];
+  if (UPDATE) {
+    for (int q = tid; q < (int)ytm; q += nthr) {
+      const int y = q / Mp, m = q - y * Mp;
+#pragma unroll
+      for (int k = 0; k < K; ++k) F[q * K + k] = (m < g.M) ? f_entry(g.mut, Lth[m], Gth[m], Lla[k], Gla[k], gnu_f, y) : 0.0;
+    }
+    __syncthreads();
+  }
   double Tfull = 0.0;
   for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[1] = wall_clock64();
+#endif
 
   // ---- pieces of a step -------------------------------------------------------------------------------------------
   // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749)
@@ -220,50 +256,21 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   };
   // w2_k(m, y) = z2 / (z1 + z2), z1 = G_theta_m G_lambda_k, z2 = G_nu y (model.py:694-696; 0 at y = 0 and where both vanish)
   const double gnu_cur = a.par[o.sc + SC_G_NU];
-  const double* Gthg = a.par + o.G_th + (size_t)l * Mp;
   auto w2_at = [&](unsigned ym, int k) SL_INL -> double {
     unsigned y = (unsigned)((float)ym * rcp_mp);
     if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
-    const double z2 = gnu_cur * (double)y, den = Gthg[ym - y * (unsigned)Mp] * Gla[k] + z2;
+    const double z2 = gnu_cur * (double)y, den = Gth[ym - y * (unsigned)Mp] * Gla[k] + z2;
     return (y == 0u || den == 0.0) ? 0.0 : z2 / den;
   };
   // the K factors of a (y, m) row that may lie beyond the LDS levels
-  auto f_row_any = [&](unsigned ym, double (&f)[K]) SL_INL {
-    const bool far = ym >= ytm;
-    const unsigned il = (far ? 0u : ym) * K;
+  // the factors of a row beyond the LDS levels: the formula of the table, from the per-reporter tables (K divides, no memory)
+  auto f_far = [&](unsigned ym, double (&f)[K]) SL_INL {
+    unsigned y = (unsigned)((float)ym * rcp_mp);
+    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const unsigned m = ym - y * (unsigned)Mp;
+    const double lt = Lth[m], gt = Gth[m];
 #pragma unroll
-    for (int k = 0; k < K; ++k) f[k] = F[il + k];
-    if (__any(far)) {
-      if (far) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) f[k] = Fl[(size_t)ym * K + k];
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the value must not cross the join as a pending load
-        asm volatile("" ::: "memory");
-      }
-    }
-  };
-  // one report into H, any level, with the deficit x (1 - sum rho) of an irregular tie in slot 0 (global)
-  auto h_add_any = [&](unsigned ym, const double (&xr)[K], double xd, bool on) SL_INL {
-    if (on) {
-      if (ym < hcm) {
-#pragma unroll
-        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], xr[k]);
-      } else {
-        double* d = Hl + (size_t)ym * K;
-#pragma unroll
-        for (int k = 1; k < K; ++k) atomicAdd(&d[k], xr[k]);
-        asm volatile("" ::: "memory");
-        if (a.nu_acc) {   // (the LDS levels' share is taken when they are flushed)
-          const double w0 = w2_at(ym, 0);
-#pragma unroll
-          for (int k = 1; k < K; ++k) a0_far += (w2_at(ym, k) - w0) * xr[k];
-        }
-      }
-      if (xd != 0.0) {
-        atomicAdd(&Hl[(size_t)ym * K], xd);
-        if (a.nu_acc) a0_far -= w2_at(ym, 0) * xd;
-      }
-    }
+    for (int k = 0; k < K; ++k) f[k] = f_entry(g.mut, lt, gt, Lla[k], Gla[k], gnu_f, (int)y);
   };
   // sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps, eps alone outside R  (model.py:967-995)
   auto elbo_inner = [&](unsigned ent, const double (&er)[K]) SL_INL -> double {
@@ -328,70 +335,63 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   auto deficit = [&](unsigned ent, double dfc) SL_INL {
     const unsigned x = SL_X(ent);
     if (x != 0u && dfc != 0.0) {
-      atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);
-      if (a.nu_acc) a0_far -= w2_at(SL_YM(ent), 0) * ((double)x * dfc);
+      atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);   // (its share of nu: nu_far, below)
+      dflag = true;
     }
   };
-  auto near1 = [&](unsigned ent, double (&U)[K]) SL_INL {
-    const double dx = (double)SL_X(ent);
-#pragma unroll
-    for (int k = 0; k < K; ++k) U[k] = fma(dx, F[SL_YM(ent) * K + k], U[k]);
-  };
-  // one report, any level: the general walks
-  auto gen1 = [&](unsigned ent, double (&U)[K]) SL_INL {
-    double f[K];
-    f_row_any(SL_YM(ent), f);
-    const double dx = (double)SL_X(ent);
-#pragma unroll
-    for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
-  };
-  auto gen2 = [&](unsigned ent, const double (&r)[K], const double (&er)[K], double dfc) SL_INL {
-    const unsigned x = SL_X(ent);
-    const double dx = (double)x;
-    double xr[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) xr[k] = dx * r[k];
-    if (a.do_hist) h_add_any(SL_YM(ent), xr, dx * dfc, x != 0u);
-    if (ELBO) e_log += dx * log_tab(elbo_inner(ent, er), lt);
-  };
-
   // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
   auto body = [&](auto rct) SL_INL {
     constexpr int RCT = decltype(rct)::value;
-    constexpr int NP = RCT < 0 ? SL_PF : RCT;   // rounds held in registers
+    constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
     const size_t row0 = (size_t)s * 64;
     const bool act = (unsigned)row0 + (unsigned)lane < T32;
     const unsigned ea_c = ea;
     const int Rr = RCT < 0 ? R : RCT;
-    const bool far = RCT < 0 && ymax >= lim_y;   // (wave-uniform; the straight-line bodies only see near steps)
     const StepIn<K> cur = P;
     // the next step: its range was loaded a step ago; its per-tie values and rounds now.  It has at most as many rounds as
     // this one (sorted order), so NP loads cover them; surplus loads read later steps' slots, unused.  After the wave's last
     // step the same loads are issued once more, of this step's own (valid) addresses: no branch around a load.
-    const long long s2 = s + GW;
+    const long long s2 = sn, s3 = draw();
     const bool more = s2 < NS;
     const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
     const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
     const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
-    fetch_range(s2 + GW < NS ? s2 + GW : s);
+    fetch_range(s3 < NS ? s3 : s);
     fetch_tie(P, more ? s2 : s);
-    fetch_ent(P, ea2, RC<NP>{});
+    if (RCT >= 0 || PFK <= 8) fetch_ent(P, ea2, RC<NP>{});
+    else {   // a general step of a wide-prefetch variant: as many blocks of 8 rounds as the next step has
+      const unsigned* pe = El + ea2;
+#pragma unroll
+      for (int j0 = 0; j0 < PFK; j0 += 8) {
+        if (j0 == 0 || j0 < R2) {   // (wave-uniform)
+#pragma unroll
+          for (int j = j0; j < j0 + 8; ++j) P.e[j] = *at_bytes(pe + j * 64, lane4);
+        }
+      }
+    }
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
-    // rounds beyond the prefetched ones: a ring of SL_RG loads in flight (clamped to the step's last round: no branch around
-    // a load)
-    unsigned rg[SL_RG];
-    auto ring_addr = [&](int j) SL_INL { return (size_t)ea_c + (unsigned)lane + (unsigned)(j < Rr ? j : Rr - 1) * 64; };
-    auto ring_fill = [&]() SL_INL {
+    // The rounds of a general step, ONE loop for all of them so that the per-round code exists PFK times and no more (a
+    // body of tens of kilobytes does not stay in the instruction cache: a cut with the prefetched rounds and the ring walked
+    // by separate code, far levels handled in line, was 68-183 KB per kernel and spent a third of its wave time waiting to
+    // issue).  The ring starts from the prefetched rounds and keeps PFK loads in flight over the further ones, clamped
+    // to the step's last round: no branch around a load.  use(c, GB entries) for groups of GB rounds, in order; rounds past
+    // the last are empty entries (x = 0, row 0).
+    auto ring_addr = [&](int j) SL_INL { const int jj = j < Rr ? j : (Rr > 0 ? Rr - 1 : 0); return (size_t)ea_c + (unsigned)lane + (unsigned)jj * 64; };
+    auto rounds = [&](auto gbc, auto&& use) SL_INL {
+      constexpr int GB = decltype(gbc)::value;
+      unsigned rg[PFK];   // the ring: PFK loads in flight, starting from the prefetched rounds
 #pragma unroll
-      for (int i = 0; i < SL_RG; ++i) rg[i] = El[ring_addr(SL_PF + i)];
-    };
-    auto ring_walk = [&](auto&& use) SL_INL {   // use(entry) for rounds SL_PF .. Rr-1, in order
-      for (int j0 = SL_PF; j0 < Rr; j0 += SL_RG) {
+      for (int i = 0; i < PFK; ++i) rg[i] = cur.e[i];
+      for (int j0 = 0; j0 < Rr; j0 += PFK) {
 #pragma unroll
-        for (int i = 0; i < SL_RG; ++i) {
-          const unsigned c = rg[i];
-          rg[i] = El[ring_addr(j0 + i + SL_RG)];
-          if (j0 + i < Rr) use(c);   // (wave-uniform)
+        for (int gi = 0; gi < PFK; gi += GB) {
+          unsigned c[GB];
+#pragma unroll
+          for (int u = 0; u < GB; ++u) {
+            c[u] = (j0 + gi + u < Rr) ? rg[gi + u] : 0u;   // (wave-uniform select)
+            rg[gi + u] = El[ring_addr(j0 + gi + u + PFK)];
+          }
+          if (j0 + gi < Rr) use(c);   // (wave-uniform)
         }
       }
     };
@@ -413,33 +413,46 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
 #pragma unroll
       for (int k = 0; k < K; ++k) U[k] = 0.0;
 #ifdef SL_DEBUG   // timing experiments (results are wrong): VMR_DEBUG bit 16 = no walk 1, 32 = no walk 2, 8 = no H flush
-      if (g.dbg & 16) { if (RCT < 0 && Rr > SL_PF) ring_fill(); }
-      else
+      if (g.dbg & 16) {} else
 #endif
       if (RCT >= 0) walk1_near(cur.e, RC<NP>{}, U);
-      else if (far) {
+      else {
+        // A general step.  Kept SMALL: every round's code exists once per position of a group, and a body of tens of
+        // kilobytes does not stay in the instruction cache (a cut with 24 prefetched rounds: 68-183 KB per kernel, a third
+        // of the wave time waiting to issue).  Groups of GB rounds read the table for the lanes whose rows are in LDS (the
+        // others read row 0 with x = 0); lanes whose row lies beyond take the table's formula, per entry and only where some
+        // lane needs it.  Rounds past the step's last are empty entries.
+        constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
+        rounds(RC<GB>{}, [&](const unsigned (&c)[GB]) SL_INL {
+          if (lim1 == 0xffffffffu) { walk1_near(c, RC<GB>{}, U); return; }
+          double f[GB][K];
+          bool fr[GB];
 #pragma unroll
-        for (int j = 0; j < SL_PF; ++j) if (j < Rr) gen1(cur.e[j], U);
-        if (Rr > SL_PF) { ring_fill(); ring_walk([&](unsigned c) SL_INL { gen1(c, U); }); }
-      } else {
+          for (int u = 0; u < GB; ++u) {
+            const unsigned ym = SL_YM(c[u]);
+            fr[u] = ym >= ytm;
 #pragma unroll
-        for (int j = 0; j < SL_PF; ++j) if (j < Rr) near1(cur.e[j], U);   // (a general step of few rounds: not the hot path)
-        if (Rr > SL_PF) {
-          ring_fill();
-          constexpr int GB = Batch<K>::value < SL_RG ? Batch<K>::value : SL_RG;
-          for (int j0 = SL_PF; j0 < Rr; j0 += SL_RG) {
+            for (int k = 0; k < K; ++k) f[u][k] = F[(fr[u] ? 0u : ym) * K + k];
+          }
 #pragma unroll
-            for (int gi = 0; gi < SL_RG; gi += GB) {
-              unsigned c[GB];
+          for (int u = 0; u < GB; ++u) {
+            const double dx = fr[u] ? 0.0 : (double)SL_X(c[u]);
 #pragma unroll
-              for (int u = 0; u < GB; ++u) {
-                c[u] = (j0 + gi + u < Rr) ? rg[gi + u] : 0u;   // (wave-uniform select; an empty entry adds 0 * F[0])
-                rg[gi + u] = El[ring_addr(j0 + gi + u + SL_RG)];
+            for (int k = 0; k < K; ++k) U[k] = fma(dx, f[u][k], U[k]);
+          }
+#pragma unroll
+          for (int u = 0; u < GB; ++u) {
+            if (__any(fr[u])) {   // (some lane's row lies beyond the LDS levels: the table's formula for those lanes)
+              if (fr[u]) {
+                double ff[K];
+                f_far(SL_YM(c[u]), ff);
+                const double dx = (double)SL_X(c[u]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) U[k] = fma(dx, ff[k], U[k]);
               }
-              if (j0 + gi < Rr) walk1_near(c, RC<GB>{}, U);
             }
           }
-        }
+        });
       }
       // ---- per-tie update from the finished sums
       double aa[K];
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
         const double d = aa[1] - aa[0];
         const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
         if (__all(safe)) {
-          const double e = exp_tab(d, xt);
+          const double e = exp_tab(d, xt);   // (a table-free degree-13 polynomial was measured 17 % slower per launch)
           r[0] = rcp_nr2(1.0 + e);   // (1 + e in [1, e^700]: no scaling needed)
           r[1] = e * r[0];
           done = true;
@@ -524,9 +537,29 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
           for (int j = 0; j < NP; ++j) deficit(cur.e[j], dfc);
         }
       } else {
+        // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
+        // beyond the levels and deficits of ties whose rho does not sum to 1 go to global memory, per entry and only where
+        // some lane needs it
+        rounds(RC<1>{}, [&](const unsigned (&c1)[1]) SL_INL {
+          const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
+          const bool fr = lim2 != 0xffffffffu && ym >= hcm;
+          const double dx = fr ? 0.0 : (double)x;
+          if (a.do_hist) {
+            const unsigned row = fr ? 0u : ym;
 #pragma unroll
-        for (int j = 0; j < SL_PF; ++j) if (j < Rr) gen2(cur.e[j], r, er, dfc);
-        if (Rr > SL_PF) { ring_fill(); ring_walk([&](unsigned c) SL_INL { gen2(c, r, er, dfc); }); }   // (the same rounds again: from the L2)
+            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + row], dx * r[k]);
+            if (irr || __any(fr)) {   // (rare) rows beyond the LDS levels, deficits of irregular ties: global adds.  Their share
+              if (fr && x != 0u) {    // of nu is taken from the global table by the grid's last workgroup (nu_far).
+                double* d = Hl + (size_t)ym * K;
+#pragma unroll
+                for (int k = 1; k < K; ++k) atomicAdd(&d[k], (double)x * r[k]);
+              }
+              if (dfc != 0.0 && x != 0u) { atomicAdd(&Hl[(size_t)ym * K], (double)x * dfc); dflag = true; }
+              asm volatile("" ::: "memory");
+            }
+          }
+          if (ELBO) e_log += (double)x * log_tab(elbo_inner(c, er), lt);
+        });
       }
     }
     if (ELBO && act) {
@@ -549,7 +582,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
     if (RCT >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);   // vmcnt(NST)
     else __builtin_amdgcn_s_waitcnt(0x0F70);                  // (general steps may add global atomics: vmcnt(0))
     // advance
-    s = s2; ea = ea2; R = R2; ymax = ym2;
+    s = s2; sn = s3; ea = ea2; R = R2; ymax = ym2;
   };
   // consecutive steps of this wave with the same number of rounds run in one straight-line loop
   auto run = [&](auto rct) SL_INL {
@@ -571,30 +604,17 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
     }
   }
 
-  __syncthreads();
 #ifdef SL_DEBUG
-  if (g.dbg & 8) {} else
+  if (dbt && lane == 0) dbt[2] = wall_clock64();
 #endif
-  if (a.do_hist) {   // flush the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
-    for (int q = tid; q < nHc; q += nthr) {
-      const double v = Hc[q];
-      if (v != 0.0) {
-        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
-        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
-      }
-    }
-  }
-  if (a.sum_a) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K])
-    double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
-    for (int q = tid; q < g.M * K; q += nthr) {
-      const double v = As[q];
-      if (v != 0.0) atomicAdd(&out[q], v);
-    }
-  }
-  if (a.nu_acc && a.do_hist == 1) {
-    // this workgroup's share of nu_shp - alpha: sum_{y>0,m,k>0} (w2_k - w2_0) H_k over its LDS levels (+ what the general
-    // code collected), then the ticket; the grid's last workgroup finishes nu (model.py:820-830)
-    double a0p = a0_far;
+  const bool nu_here = a.nu_acc && a.do_hist == 1;
+  if (nu_here && __any(dflag) && lane == 0) atomicAdd(&a.nu_acc[2 + g.L], 1.0);
+  if (nu_here) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's global adds (far levels, deficits) are performed: see nu_far
+  __syncthreads();
+  if (nu_here) {
+    // this workgroup's share of nu_shp - alpha: sum_{y>0,m,k>0} (w2_k - w2_0) H_k over its LDS levels; summed BEFORE the
+    // flush, whose float atomics the ticket below must not wait for
+    double a0p = 0.0;
     for (int q = tid; q < nHc; q += nthr) {
       const double v = Hc[q];
       if (v != 0.0) {
@@ -604,16 +624,92 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
       }
     }
     a0p = block_sum_n(a0p, red);
+    if (tid == 0) atomicAdd(&a.nu_acc[0], a0p);
+  }
+  // the flush: every wave but the first when the first draws the ticket (it then has nothing else of its own outstanding)
+  const int f0 = (nu_here && nw > 1) ? 64 : 0;
+#ifdef SL_DEBUG
+  if (g.dbg & 8) {} else
+#endif
+  if (a.do_hist && tid >= f0) {   // the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
+    for (int q = tid - f0; q < nHc; q += nthr - f0) {
+      const double v = Hc[q];
+      if (v != 0.0) {
+        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
+        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
+      }
+    }
+  }
+  if (a.sum_a && tid >= f0) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K])
+    double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
+    for (int q = tid - f0; q < g.M * K; q += nthr - f0) {
+      const double v = As[q];
+      if (v != 0.0) atomicAdd(&out[q], v);
+    }
+  }
+  if (nu_here) {
+    // the ticket; the grid's last workgroup finishes nu (model.py:820-830)
     __shared__ int nu_last;
     if (tid == 0) {
-      atomicAdd(&a.nu_acc[0], a0p);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (performed at the memory side before the ticket is drawn)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's share is performed at the memory side before the ticket is drawn)
       const double t = atomicAdd(&a.nu_acc[1], 1.0);
       nu_last = (t == (double)(gridDim.x - 1));
-      if (nu_last) {
-        double tot = atomicAdd(&a.nu_acc[0], 0.0);   // device-scope read of every workgroup's share
+      if (nu_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (nu_last) {
+      // nu_far: what went to the global table directly -- reports of levels beyond the LDS copies (categories k > 0 of rows
+      // y >= hc) and the deficits of irregular ties (slot 0 of every row) -- weighted like the rest; every workgroup's adds
+      // were performed before its ticket.  Usually all zero: the loads are the cost (Y Mp K NH values over 1024 threads).
+      double far = 0.0;
+      const size_t hcs = (size_t)g.Y * Mp * K;
+      const bool defs = atomicAdd(&a.nu_acc[2 + g.L], 0.0) != 0.0;   // some tie's rho did not sum to 1
+      const int y0 = defs ? 1 : max(1, a.hc);                         // first row that can hold anything
+      if (defs || a.hc < g.Y) {
+        for (int ll = 0; ll < g.L; ++ll) {
+          const double* H0 = a.Hg + (size_t)ll * NH * hcs;
+          const double* gthl = a.par + o.G_th + (size_t)ll * Mp;
+          for (int it = y0 * Mp + tid; it < g.Y * Mp; it += nthr) {
+            const int y = it / Mp, m = it - y * Mp;
+            const bool farrow = y >= a.hc;
+            double v0[NH], vk[NH][K > 1 ? K - 1 : 1];
+#pragma unroll
+            for (int c = 0; c < NH; ++c) {   // loads first, all in flight
+              v0[c] = defs ? H0[(size_t)c * hcs + (size_t)it * K] : 0.0;
+#pragma unroll
+              for (int k = 1; k < K; ++k) vk[c][k - 1] = farrow ? H0[(size_t)c * hcs + (size_t)it * K + k] : 0.0;
+            }
+            double h_[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) h_[k] = 0.0;
+#pragma unroll
+            for (int c = 0; c < NH; ++c) {
+              h_[0] += v0[c];
+#pragma unroll
+              for (int k = 1; k < K; ++k) h_[k] += vk[c][k - 1];
+            }
+            bool any = h_[0] != 0.0;
+#pragma unroll
+            for (int k = 1; k < K; ++k) any = any || h_[k] != 0.0;
+            if (any && m < g.M) {
+              const double z2 = gnu_cur * (double)y, gt = gthl[m];
+              const double d0 = gt * a.par[o.G_la + ll * K] + z2, w0 = d0 == 0.0 ? 0.0 : z2 / d0;
+              far -= w0 * h_[0];
+#pragma unroll
+              for (int k = 1; k < K; ++k) {
+                const double dk = gt * a.par[o.G_la + ll * K + k] + z2;
+                far += ((dk == 0.0 ? 0.0 : z2 / dk) - w0) * h_[k];
+              }
+            }
+          }
+        }
+      }
+      far = block_sum_n(far, red);
+      if (tid == 0) {
+        double tot = atomicAdd(&a.nu_acc[0], 0.0) + far;   // device-scope read of every workgroup's share
         for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
-        a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
+        a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0; a.nu_acc[2 + g.L] = 0.0;
         a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
         if (a.commit_nu) {
           double* sc = const_cast<double*>(a.par) + o.sc;
@@ -641,6 +737,9 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
       atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
     }
   }
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[3] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -653,7 +752,30 @@ static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
   const long long NS = ((long long)g.N * g.N + 63) / 64, nw = sh.tpb / 64;
   int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
   if (rc) return rc;
+#ifdef SL_DEBUG
+  // VMR_DEBUG_TIMES=<file>: every launch appends "<update><elbo> <waves>" and one line of four clock readings per wave
+  static unsigned long long* dbg_buf = nullptr;
+  const char* tf = getenv("VMR_DEBUG_TIMES");
+  const size_t nwv = (size_t)g.L * a.Gl * nw;
+  a.dbg_t = nullptr;
+  if (tf) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, (size_t)1 << 22);
+    if (nwv * 32 <= ((size_t)1 << 22)) a.dbg_t = dbg_buf;
+  }
+#endif
   hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
+#ifdef SL_DEBUG
+  if (a.dbg_t) {
+    std::vector<unsigned long long> t(nwv * 4);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipMemcpy(t.data(), dbg_buf, nwv * 32, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(tf, "a")) {
+      fprintf(f, "launch %d%d hist %d waves %zu tpb %d\n", (int)UPDATE, (int)ELBO, a.do_hist, nwv, sh.tpb);
+      for (size_t i = 0; i < nwv; ++i) fprintf(f, "%llu %llu %llu %llu\n", t[i * 4], t[i * 4 + 1], t[i * 4 + 2], t[i * 4 + 3]);
+      fclose(f);
+    }
+  }
+#endif
   return VMR_OK;
 }
 

@@ -2436,7 +2436,7 @@ static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 // Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
-  SlShape s{std::min(h->sp_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0)), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
+  SlShape s{std::max(64, std::min(h->sp_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -2444,7 +2444,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, h->Fg, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0};
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0};
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -2626,7 +2626,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     const int nh = h->h_reduced ? 1 : NH;
     const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
-                       h->slotF, h->lutg, h->sparse ? h->Fg : nullptr, h->fin_g, (h->sparse && h->sl) ? h->nu_acc : nullptr, nh,
+                       h->slotF, h->lutg, (h->sparse && !h->sl) ? h->Fg : nullptr, h->fin_g, (h->sparse && h->sl) ? h->nu_acc : nullptr, nh,
                        with_phi ? 1 : 0, consume, g);
     h->ftab_valid = h->sparse && with_phi;
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
@@ -2662,7 +2662,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
     if (!g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   }
   if (mode != 2) h->h_zero = false;
-  if (h->sparse && mode != 2) {
+  if (h->sparse && !h->sl && mode != 2) {
     if (!h->ftab_valid) {
       const int by = std::max(1, std::min(64, (g.Y * g.Mp + 255) / 256));
       hipLaunchKernelGGL(k_build_f, dim3(g.L, by), dim3(256), 0, h->stream, h->par, h->Fg, g);
@@ -2956,6 +2956,21 @@ static int mask_lists_from_words(vmr_ctx* h) {
 }
 
 // sorted lists: the per-tie arrays the sweeps read, by position (the tie-order originals stay for the mask kernels)
+// reports per level (mirror count) of the sorted lists: hist[y], y clamped to 64; empty slots (x = 0, not in R) are skipped
+__global__ __launch_bounds__(256) void k_level_hist(const unsigned* __restrict__ E, unsigned long long n, int Mp, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned long long sh[65];
+  for (int i = threadIdx.x; i < 65; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+    const unsigned e = E[i];
+    if (e == 0u) continue;
+    const unsigned y = SL_YM(e) / (unsigned)Mp;
+    atomicAdd(&sh[y < 64u ? y : 64u], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 65; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
 static int sl_finish(vmr_ctx* h) {
   const Geo& g = h->g;
   const size_t rows = (size_t)g.L * g.N * g.N;
@@ -2989,10 +3004,10 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   size_t need = 0;
   if (h->sparse && h->sl) {
     // Sorted lists: the populous levels of F (read) and H (float atomics) in LDS, shared by all waves of a workgroup; no per-wave
-    // LDS at all.  One pass per sweep when at least 4 levels of each fit at >= 16 waves per CU, else the rho pass keeps F and a
-    // statistics pass rebuilds H (two passes over the entries).
+    // LDS at all.  One pass per sweep when every level of both fits at >= 16 waves per CU (or the levels beyond hold under 0.1 %
+    // of the reports), else the rho pass keeps F and a statistics pass rebuilds H (two passes over the entries).
     auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 12)));
+    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 64)));   // as many levels as fit: with all of them in LDS nothing is "far"
     const int cap = sl_tpb_max(K, false, h->all_full != 0), wcu = 4 * sl_wpe(K, false, h->all_full != 0);   // the update variant's workgroup / waves per CU (registers)
     auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {
       const size_t b = sl_smem(g, yt, hc, upd, false, hist);
@@ -3010,8 +3025,27 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       return false;
     };
     int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
-    const bool one = best(true, true, 16, lv1, t1);
-    if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
+    bool one = best(true, true, 16, lv1, t1);
+    if (one && lv1 < want) {
+      // Not every level fits beside the other table.  A report of a level beyond the LDS ones costs its whole 64-tie round the
+      // slow path (the factor formula, a global add), so one pass only pays while such reports are rare: count the reports
+      // per level.  (BASELINE config 5 -- M = 1000, K = 3: 3 levels of each fit, 2.5 % of the reports lie beyond, four rounds
+      // of five hold one; the two passes keep 6 levels of F and 9 of H.)
+      std::vector<unsigned long long> hist(65, 0);
+      unsigned long long* hd = nullptr;
+      CK(hipMalloc(&hd, 65 * 8));
+      CK(hipMemsetAsync(hd, 0, 65 * 8, h->stream));
+      hipLaunchKernelGGL(k_level_hist, dim3(1024), dim3(256), 0, h->stream, h->E, h->n_slots, g.Mp, hd);
+      CK(hipGetLastError());
+      CK(hipMemcpyAsync(hist.data(), hd, 65 * 8, hipMemcpyDeviceToHost, h->stream));
+      CK(hipStreamSynchronize(h->stream));
+      CK(hipFree(hd));
+      unsigned long long tot = 0, far = 0;
+      for (int y = 0; y < 65; ++y) { tot += hist[y]; if (y >= lv1) far += hist[y]; }
+      if ((double)far > (double)tot / 1024.0) one = false;
+    }
+    if (getenv("VMR_TWO_PASS")) one = one && !env_i("VMR_TWO_PASS", 0);
+    if (one) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
     else {
       g.two_pass = 1;
       if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
@@ -3020,9 +3054,8 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     }
     {   // small datasets: smaller workgroups, so that the steps spread over every CU
       const long long NS = ((long long)g.N * g.N + 63) / 64;
-      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb >>= 1;
+      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb = std::max(64, (h->sp_tpb / 2) & ~63);   // (768 -> 384 -> 192 -> 64)
     }
-    if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
     g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
     g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
     { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
@@ -3089,8 +3122,8 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   CK(hipMemsetAsync(h->Hg, 0, (size_t)L * NH * g.Y * g.Mp * K * 8, h->stream));
   CK(hipMalloc(&h->elbo_dev, 8 * 8));   // [0..3] results, [4..6] scratch of k_fin_rho
   CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
-  CK(hipMalloc(&h->nu_acc, (size_t)(2 + L) * 8));   // the nu update inside the pass (SlArgs::nu_acc)
-  CK(hipMemsetAsync(h->nu_acc, 0, (size_t)(2 + L) * 8, h->stream));
+  CK(hipMalloc(&h->nu_acc, (size_t)(3 + L) * 8));   // the nu update inside the pass (SlArgs::nu_acc)
+  CK(hipMemsetAsync(h->nu_acc, 0, (size_t)(3 + L) * 8, h->stream));
   CK(hipMalloc(&h->fin_g, (size_t)L * (2 * KMAX + 2) * 8));   // k_fin_gamma: per layer 2 K sums and a ticket
   CK(hipMemsetAsync(h->fin_g, 0, (size_t)L * (2 * KMAX + 2) * 8, h->stream));
   CK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));

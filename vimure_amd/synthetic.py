@@ -486,7 +486,10 @@ class PosteriorSyntheticNetwork:
         self.theta_shp, self.theta_rte = model.gamma_shp_f, model.gamma_rte_f
         self.lambda_shp, self.lambda_rte = model.phi_shp_f, model.phi_rte_f
         self.mutuality_shp, self.mutuality_rte = model.nu_shp_f, model.nu_rte_f
-        self.L, self.N, self.K = model.L, model.N, model.K
+        if self.rho is not None:
+            self.L, self.N, self.K = self.rho.shape[0], self.rho.shape[1], self.rho.shape[3]   # (synthetic.py:1037 reads rho_f's shape)
+        else:
+            self.L, self.N, self.K = model.L, model.N, model.K
         self.M = self.theta_shp.shape[1]
 
     def build_Y(self):
