@@ -5,7 +5,7 @@
 #include <vector>
 
 template <int MODE>
-__global__ __launch_bounds__(256) void kern(double* out, int iters, int active, int pattern) {
+__global__ __launch_bounds__(256) void kern(double* out, int iters, int active, int pattern, double addend) {
   __shared__ double sh[4096];
   const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 4096; i += 256) sh[i] = 0.0;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void kern(double* out, int iters, int active, 
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
     if (on) {
-      if (MODE == 0) atomicAdd(&sh[idx], 1.0);
+      if (MODE == 0) atomicAdd(&sh[idx], addend);
       else if (MODE == 1) atomicAdd(reinterpret_cast<unsigned long long*>(&sh[idx]), 1ull);
       else if (MODE == 2) atomicAdd(reinterpret_cast<float*>(&sh[idx]), 1.0f);
       else if (MODE == 3) atomicAdd(reinterpret_cast<unsigned*>(&sh[idx]), 1u);
@@ -46,14 +46,17 @@ int main() {
   const char* mn[] = {"ds_add_f64", "ds_add_u64", "ds_add_f32", "ds_add_u32", "ds_write_b64", "read+write b64"};
   const char* pn[] = {"contig", "pairs", "quads", "random", "one addr", "stride16B"};
   const int iters = 2000;
-  for (int wgs : {1, 2}) {   // workgroups per CU (4 waves each)
+  for (double addend : {1.0, 0.0, 1e-310, 1e-200})
+  for (int wgs : {1, 2}) {
+    if (addend != 1.0 && wgs != 2) continue;
+    printf("addend %g\n", addend);   // workgroups per CU (4 waves each)
     printf("== %d workgroup(s) of 4 waves per CU: cycles per wave-instruction, as seen by one wave (x waves per CU for the LDS cost)\n", wgs);
-    for (int mode = 0; mode < 6; ++mode)
+    for (int mode = 0; mode < (addend == 1.0 ? 6 : 1); ++mode)
       for (int pat = 0; pat < 6; ++pat)
         for (int act : {64, 32, 16, 8}) {
           if (pat != 0 && act != 64) continue;
-          void (*k)(double*, int, int, int) = mode == 0 ? kern<0> : mode == 1 ? kern<1> : mode == 2 ? kern<2> : mode == 3 ? kern<3> : mode == 4 ? kern<4> : kern<5>;
-          hipLaunchKernelGGL(k, dim3(256 * wgs), dim3(256), 0, 0, d, iters, act, pat);
+          void (*k)(double*, int, int, int, double) = mode == 0 ? kern<0> : mode == 1 ? kern<1> : mode == 2 ? kern<2> : mode == 3 ? kern<3> : mode == 4 ? kern<4> : kern<5>;
+          hipLaunchKernelGGL(k, dim3(256 * wgs), dim3(256), 0, 0, d, iters, act, pat, addend);
           hipDeviceSynchronize();
           std::vector<double> h(256 * wgs);
           hipMemcpy(h.data(), d, 8 * 256 * wgs, hipMemcpyDeviceToHost);

@@ -48,8 +48,8 @@ struct SlArgs {
   // The nu update inside the pass (model.py:820-830): nu_shp - alpha = sum x rho_k w2_k is a linear functional of the
   // statistics H the pass holds, so every workgroup adds its share to nu_acc[0] and the grid's last one (ticket nu_acc[1])
   // finishes nu -- no finalize launch on plain sweeps.  nu_acc[2 + l] = sum_{y,m} w2_0 C[l][y][m], the part that comes from
-  // the constant C (H_0 = C - sum_{k>0} H_k), left there by k_fin_gamma; nu_acc[2 + L] != 0: some workgroup sent a deficit to
-  // the global table.  null: the pass does not touch nu.
+  // the constant C (H_0 = C - D - sum_{k>0} H_k, D: the deficits of ties whose rho does not sum to 1), left there by
+  // k_fin_gamma.  null: the pass does not touch nu.
   double* nu_acc; double* elbo_dev; int commit_nu;
 #ifdef SL_DEBUG
   unsigned long long* dbg_t;   // [waves][4]: a wave's start, end of prologue, end of step loop, end (100 MHz clock)
@@ -62,13 +62,18 @@ struct SlShape { int tpb, yt, hc; size_t smem; };
 // ELBO variants carry the logarithms' on top, so the kernels are compiled for fewer, fatter waves as K grows -- no variant
 // spills (profiles/r03_kernel_resources.md).  Largest workgroup / waves per SIMD the kernel<K, ., ELBO, .> is compiled for:
 // (allfull: every mask row is all ones -- the variants without the mask code need a few registers fewer)
-constexpr int sl_tpb_max(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 512 : 256) : ((K <= 2 && allfull) ? 1024 : (K <= 4 ? 768 : 512)); }
-constexpr int sl_wpe(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 2 : 1) : ((K <= 2 && allfull) ? 4 : (K <= 4 ? 3 : 2)); }
+constexpr bool sl_light(int K, bool elbo, bool allfull, bool update) { return !elbo && allfull && (K <= 2 || (!update && K <= 4)); }   // fits 128 registers
+constexpr int sl_tpb_max(int K, bool elbo, bool allfull, bool update = true) {
+  return elbo ? (K <= 4 ? 512 : 256) : (sl_light(K, elbo, allfull, update) ? 1024 : (K <= 4 ? 768 : 512));
+}
+constexpr int sl_wpe(int K, bool elbo, bool allfull, bool update = true) {
+  return elbo ? (K <= 4 ? 2 : 1) : (sl_light(K, elbo, allfull, update) ? 4 : (K <= 4 ? 3 : 2));
+}
 
 // LDS bytes of one workgroup of the sweep kernel
 static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
-  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (size_t)g.Mp * 8 * (update ? 2 : 1) +
+  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * lb : 0) + (size_t)g.Mp * 8 * (update ? 2 : 1) +
          (size_t)g.W * 8 + 128 + (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
 }
 

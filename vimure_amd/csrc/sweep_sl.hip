@@ -59,7 +59,7 @@ __device__ __forceinline__ double rcp_nr2(double d) {
 template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 : (K <= 4 ? 4 : 2); };
 
 template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
-__global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL)) void k_sweep_sl(SlArgs a, Geo g) {
+__global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL, UPDATE)) void k_sweep_sl(SlArgs a, Geo g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   const unsigned hcm = a.do_hist ? (unsigned)a.hc * (unsigned)Mp : 0u;  // rows of H held in LDS
   size_t off = 0;
   double* F = reinterpret_cast<double*>(smem + off); off += (size_t)ytm * K * 8;            // [yt][Mp][K]
-  const int nHc = (int)hcm * (K - 1);
-  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                // [K-1][hc][Mp]
+  const int nHc = (int)hcm * K;
+  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                // [K][hc][Mp]: plane 0 = deficits, k = category k
   // per-reporter tables: G_theta (the factor table, the ELBO's inner sums, the nu weights) and E[log theta] (the factor table)
   double* Gth = reinterpret_cast<double*>(smem + off); off += (size_t)Mp * 8;
   double* Lth = reinterpret_cast<double*>(smem + off); off += UPDATE ? (size_t)Mp * 8 : 0;
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   const double eps = g.eps;
   const float rcp_mp = 1.0f / (float)Mp;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
-  bool dflag = false;   // this lane sent a deficit to the global table (tells the grid's last workgroup to look: nu_far)
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   // first two tickets of a wave are fixed -- wv and nw + wv -- so that its first loads go out before the tables are built.
   const long long Gl_ = a.Gl;
   unsigned* tick = reinterpret_cast<unsigned*>(smem + off); off += 16;
-  if (tid == 0) *tick = 2u * (unsigned)nw;
+  if (tid == 0) { tick[0] = 2u * (unsigned)nw; tick[1] = 0u; }   // ([1]: some step of this workgroup added a deficit)
   auto step_of = [&](unsigned t) SL_INL -> long long { return (long long)gb + (long long)t * Gl_; };
   auto draw = [&]() SL_INL -> long long {   // this wave's next ticket (one LDS atomic by lane 0)
     unsigned t = 0u;
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
           const double dx = (double)SL_X(e[j0 + u]);
           if (a.do_hist) {
 #pragma unroll
-            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
+            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)k * hcm + ym], dx * r[k]);
           }
           if (ELBO) in_[u] = elbo_inner(e[j0 + u], er);
         }
@@ -331,13 +330,11 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
       }
     }
   };
-  // the deficits x (1 - sum_k rho_k) of ties whose rho does not sum to 1 go to slot 0 of H (global; rare)
-  auto deficit = [&](unsigned ent, double dfc) SL_INL {
-    const unsigned x = SL_X(ent);
-    if (x != 0u && dfc != 0.0) {
-      atomicAdd(&Hl[(size_t)SL_YM(ent) * K], (double)x * dfc);   // (its share of nu: nu_far, below)
-      dflag = true;
-    }
+  // the deficits x (1 - sum_k rho_k) of ties whose rho does not sum to 1 go to plane 0 of H.  (In LDS like the rest: the true
+  // edges of BASELINE config 5 -- 1000 reports each, every exponential underflows, the reference's all-zero rows -- sent 40 M
+  // adds per pass to a few thousand addresses of the global table when this was a global add.)
+  auto deficit = [&](unsigned ent, double dfc) SL_INL {   // (a step whose rows all lie in the LDS levels)
+    atomicAdd(&Hc[SL_YM(ent)], (double)SL_X(ent) * dfc);
   };
   // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
   auto body = [&](auto rct) SL_INL {
@@ -497,6 +494,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
           dfc = 1.0 - sm;
           if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;
           irr = __any(dfc != 0.0);
+          if (irr && lane == 0) tick[1] = 1u;
         }
       }
       // exactly NST store instructions on every path, no mask (the wait at the bottom of the step counts on it): positions
@@ -515,6 +513,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
       dfc = 1.0 - sm;
       if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;
       irr = __any(dfc != 0.0);
+      if (irr && lane == 0) tick[1] = 1u;
       if (!ELBO && a.do_hist == 1 && act && (ALLFULL || cls == 1u)) {   // all-ones mask rows are summed here too
 #pragma unroll
         for (int k = 0; k < K; ++k) accF[k] += r[k];
@@ -538,8 +537,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
         }
       } else {
         // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
-        // beyond the levels and deficits of ties whose rho does not sum to 1 go to global memory, per entry and only where
-        // some lane needs it
+        // beyond the levels go to global memory, per entry and only where some lane needs it
         rounds(RC<1>{}, [&](const unsigned (&c1)[1]) SL_INL {
           const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
           const bool fr = lim2 != 0xffffffffu && ym >= hcm;
@@ -547,14 +545,15 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
           if (a.do_hist) {
             const unsigned row = fr ? 0u : ym;
 #pragma unroll
-            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + row], dx * r[k]);
-            if (irr || __any(fr)) {   // (rare) rows beyond the LDS levels, deficits of irregular ties: global adds.  Their share
-              if (fr && x != 0u) {    // of nu is taken from the global table by the grid's last workgroup (nu_far).
+            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)k * hcm + row], dx * r[k]);
+            if (irr) atomicAdd(&Hc[row], dx * dfc);   // (wave-uniform: some tie of the step does not sum to 1)
+            if (__any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
+              if (fr && x != 0u) {   // table by the grid's last workgroup (nu_far).
                 double* d = Hl + (size_t)ym * K;
 #pragma unroll
                 for (int k = 1; k < K; ++k) atomicAdd(&d[k], (double)x * r[k]);
+                if (dfc != 0.0) atomicAdd(&d[0], (double)x * dfc);
               }
-              if (dfc != 0.0 && x != 0u) { atomicAdd(&Hl[(size_t)ym * K], (double)x * dfc); dflag = true; }
               asm volatile("" ::: "memory");
             }
           }
@@ -608,19 +607,18 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
   if (dbt && lane == 0) dbt[2] = wall_clock64();
 #endif
   const bool nu_here = a.nu_acc && a.do_hist == 1;
-  if (nu_here && __any(dflag) && lane == 0) atomicAdd(&a.nu_acc[2 + g.L], 1.0);
   if (nu_here) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's global adds (far levels, deficits) are performed: see nu_far
   __syncthreads();
   if (nu_here) {
-    // this workgroup's share of nu_shp - alpha: sum_{y>0,m,k>0} (w2_k - w2_0) H_k over its LDS levels; summed BEFORE the
-    // flush, whose float atomics the ticket below must not wait for
+    // this workgroup's share of nu_shp - alpha: sum_{y>0,m} [sum_{k>0} (w2_k - w2_0) H_k - w2_0 D] over its LDS levels (D: the
+    // deficits, plane 0); summed BEFORE the flush, whose float atomics the ticket below must not wait for
     double a0p = 0.0;
-    for (int q = tid; q < nHc; q += nthr) {
+    for (int q = (tick[1] ? 0 : (int)hcm) + tid; q < nHc; q += nthr) {   // (plane 0 only when something was added to it)
       const double v = Hc[q];
       if (v != 0.0) {
-        const int k1 = q / (int)hcm;
-        const unsigned ym = (unsigned)(q - k1 * (int)hcm);
-        a0p += (w2_at(ym, k1 + 1) - w2_at(ym, 0)) * v;
+        const int k = q / (int)hcm;
+        const unsigned ym = (unsigned)(q - k * (int)hcm);
+        a0p += ((k ? w2_at(ym, k) : 0.0) - w2_at(ym, 0)) * v;
       }
     }
     a0p = block_sum_n(a0p, red);
@@ -631,12 +629,12 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
 #ifdef SL_DEBUG
   if (g.dbg & 8) {} else
 #endif
-  if (a.do_hist && tid >= f0) {   // the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
-    for (int q = tid - f0; q < nHc; q += nthr - f0) {
+  if (a.do_hist && tid >= f0) {   // the LDS levels ([K][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
+    for (int q = (tick[1] ? 0 : (int)hcm) + tid - f0; q < nHc; q += nthr - f0) {
       const double v = Hc[q];
       if (v != 0.0) {
-        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
-        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
+        const int k = q / (int)hcm, ym = q - k * (int)hcm;
+        atomicAdd(&Hl[(size_t)ym * K + k], v);
       }
     }
   }
@@ -659,26 +657,24 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
     }
     __syncthreads();
     if (nu_last) {
-      // nu_far: what went to the global table directly -- reports of levels beyond the LDS copies (categories k > 0 of rows
-      // y >= hc) and the deficits of irregular ties (slot 0 of every row) -- weighted like the rest; every workgroup's adds
-      // were performed before its ticket.  Usually all zero: the loads are the cost (Y Mp K NH values over 1024 threads).
+      // nu_far: what went to the global table directly -- reports of levels beyond the LDS copies (rows y >= hc: categories
+      // k > 0 and, in slot 0, the deficits of irregular ties) -- weighted like the rest; every workgroup's adds were performed
+      // before its ticket.  Usually all zero: the loads are the cost ((Y - hc) Mp K NH values over the workgroup).
       double far = 0.0;
       const size_t hcs = (size_t)g.Y * Mp * K;
-      const bool defs = atomicAdd(&a.nu_acc[2 + g.L], 0.0) != 0.0;   // some tie's rho did not sum to 1
-      const int y0 = defs ? 1 : max(1, a.hc);                         // first row that can hold anything
-      if (defs || a.hc < g.Y) {
+      const int y0 = max(1, a.hc);   // first row that can hold anything
+      if (a.hc < g.Y) {
         for (int ll = 0; ll < g.L; ++ll) {
           const double* H0 = a.Hg + (size_t)ll * NH * hcs;
           const double* gthl = a.par + o.G_th + (size_t)ll * Mp;
           for (int it = y0 * Mp + tid; it < g.Y * Mp; it += nthr) {
             const int y = it / Mp, m = it - y * Mp;
-            const bool farrow = y >= a.hc;
             double v0[NH], vk[NH][K > 1 ? K - 1 : 1];
 #pragma unroll
             for (int c = 0; c < NH; ++c) {   // loads first, all in flight
-              v0[c] = defs ? H0[(size_t)c * hcs + (size_t)it * K] : 0.0;
+              v0[c] = H0[(size_t)c * hcs + (size_t)it * K];
 #pragma unroll
-              for (int k = 1; k < K; ++k) vk[c][k - 1] = farrow ? H0[(size_t)c * hcs + (size_t)it * K + k] : 0.0;
+              for (int k = 1; k < K; ++k) vk[c][k - 1] = H0[(size_t)c * hcs + (size_t)it * K + k];
             }
             double h_[K];
 #pragma unroll
@@ -709,7 +705,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL), (K == 2 && !ELBO && A
       if (tid == 0) {
         double tot = atomicAdd(&a.nu_acc[0], 0.0) + far;   // device-scope read of every workgroup's share
         for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
-        a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0; a.nu_acc[2 + g.L] = 0.0;
+        a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
         a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
         if (a.commit_nu) {
           double* sc = const_cast<double*>(a.par) + o.sc;

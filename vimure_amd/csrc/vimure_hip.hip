@@ -2436,7 +2436,7 @@ static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 // Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
-  SlShape s{std::max(64, std::min(h->sp_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
+  SlShape s{std::max(64, std::min((update || elbo) ? h->sp_tpb : h->st_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0, update)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -3008,15 +3008,17 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     // of the reports), else the rho pass keeps F and a statistics pass rebuilds H (two passes over the entries).
     auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
     const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 64)));   // as many levels as fit: with all of them in LDS nothing is "far"
-    const int cap = sl_tpb_max(K, false, h->all_full != 0), wcu = 4 * sl_wpe(K, false, h->all_full != 0);   // the update variant's workgroup / waves per CU (registers)
+    // a variant's largest workgroup / waves per CU (registers): the statistics-only variant is lighter than the update's
+    auto cap_of = [&](bool upd) { return sl_tpb_max(K, false, h->all_full != 0, upd); };
+    auto wcu_of = [&](bool upd) { return 4 * sl_wpe(K, false, h->all_full != 0, upd); };
     auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {
       const size_t b = sl_smem(g, yt, hc, upd, false, hist);
-      if (b > SP_LDS_MAX || tpb > cap) return 0;
-      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), wcu / nw);
+      if (b > SP_LDS_MAX || tpb > cap_of(upd)) return 0;
+      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), wcu_of(upd) / nw);
       return wgs * nw;
     };
     auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {
-      min_waves = std::min(min_waves, wcu);
+      min_waves = std::min(min_waves, wcu_of(upd));
       for (int lv = want; lv >= 1; --lv) {
         int bw = 0, bt = 256;
         for (int tpb : {1024, 768, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
@@ -3045,20 +3047,22 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       if ((double)far > (double)tot / 1024.0) one = false;
     }
     if (getenv("VMR_TWO_PASS")) one = one && !env_i("VMR_TWO_PASS", 0);
-    if (one) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
+    if (one) { g.yt = g.hc = lv1; h->sp_tpb = h->st_tpb = t1; }
     else {
       g.two_pass = 1;
       if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
       if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
-      g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
+      g.yt = lvr; g.hc = lvh; h->sp_tpb = tr; h->st_tpb = th;
     }
     {   // small datasets: smaller workgroups, so that the steps spread over every CU
       const long long NS = ((long long)g.N * g.N + 63) / 64;
-      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb = std::max(64, (h->sp_tpb / 2) & ~63);   // (768 -> 384 -> 192 -> 64)
+      for (int* t : {&h->sp_tpb, &h->st_tpb})
+        while (*t > 64 && NS * L < (long long)h->ncu * (*t / 64)) *t = std::max(64, (*t / 2) & ~63);   // (768 -> 384 -> 192 -> 64)
     }
     g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
     g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
     { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
+    { const int t = env_i("VMR_ST_TPB", h->st_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->st_tpb = t; }
     for (int v = 0; v < 4; ++v) need = std::max(need, sl_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
     CK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
   } else if (h->sparse) {

@@ -82,7 +82,8 @@ struct vmr_ctx {
   double* Fg = nullptr;        // [L][Y][Mp][K] per-report factors of the rho update (k_build_f / k_fin_gamma)
   bool ftab_valid = false;     // Fg matches the current parameters
   double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
-  int sp_tpb = 256;            // threads per workgroup of k_rho_sp
+  int sp_tpb = 256;            // threads per workgroup of the report-list passes that update rho or reduce the ELBO
+  int st_tpb = 256;            // ... of the statistics-only pass (a lighter variant: bigger workgroups)
   unsigned* Qt = nullptr;      // [L][N*N] sum_m R[t,m] X[mirror(t),m]
   unsigned long long* ebase = nullptr;   // device [L]
   unsigned long long nnz = 0;  // non-zero counts in X
