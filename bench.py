@@ -308,7 +308,8 @@ def c5_layer_block(device, N=8000, M=1000, K=3, sweeps=10):
 def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
     """BASELINE configs[3] shape (tools/bench_batch.py): Karnataka-like villages (self-reporter mask, M-dim = N, 4 layers fitted
     separately, K=2, 5 realisations x <= 101 iterations per fit; karnataka.py:170-191) through vimure_amd.batch from ONE
-    process.  Outside the timed region of `value`."""
+    process: the 16 (village, layer) units advance in lockstep, one launch per kernel and sweep for all of them
+    (vmr_fit_loop_batch), the seeds one after the other.  Outside the timed region of `value`."""
     import warnings
     from vimure_amd.batch import fit_datasets
     from vimure_amd.synthetic import standard_sbm
@@ -324,7 +325,7 @@ def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
     dt = time.perf_counter() - t0
     sweeps = float(df["iters"].sum())   # (iterations of the best realisation only: a lower bound on the sweeps run)
     return {"workload": f"{len(sizes)} villages N={list(sizes)} x 4 layers x {n_seeds} seeds, 5 realisations x <= 101 iterations each",
-            "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": 8,
+            "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": 8, "lockstep_units": 4 * len(sizes),
             "mean_fit_seconds": float(df["seconds"].mean()), "sweeps_per_s_lower_bound": sweeps / dt}
 
 

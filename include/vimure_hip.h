@@ -129,6 +129,17 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out);
 int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter, double* row_elbo,
                  double* row_runtime, int* row_reached, double* elbo, int* iters, int* converged);
 
+/* The same loop for n handles in lockstep -- the realisations of many small fits (the reference's Karnataka experiment,
+ * notebooks/python/experiments/karnataka.py:170-191: a village layer of N = 200-800 is two dependent 20-40 us launches per
+ * sweep that leave the GPU nearly empty).  Every handle must have had its vmr_set_state.  The handles of the first one's kind
+ * (report lists in one pass, same K / mutuality / mask kind, same device) share ONE launch of each kernel per sweep, their
+ * ELBOs come back in one copy, a handle that converges leaves the launch; handles of another kind run their loops one after the
+ * other.  Each handle's results are exactly those of vmr_fit_loop.  Arrays are per handle: n_rows[n], row_*[n * cap] (handle u
+ * at u * cap), elbo[n], iters[n], converged[n], rc[n] (a handle's own return code; its message via vmr_last_error).  Returns the
+ * first non-zero rc, else VMR_OK.  Replaces n calls of model.py:405-426 running side by side. */
+int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter,
+                       double* row_elbo, double* row_runtime, int* row_reached, double* elbo, int* iters, int* converged, int* rc);
+
 /* Stand-alone ELBO of the current state (model.py:948-1019 incl. the stale G_exp_nu of
  * model.py:970).  Synchronises.  Returns VMR_ENAN when the value is NaN. */
 int vmr_elbo(vmr_handle h, double* out);

@@ -1,0 +1,75 @@
+"""GPU: the lockstep loop of many small fits (vmr_fit_loop_batch: one launch per kernel and sweep for all handles) gives every
+handle exactly what its own vmr_fit_loop gives (reference model.py:405-426, 1021-1056 per fit)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _village(N, seed, K=2, L=1):
+    from vimure_amd.synthetic import standard_sbm
+    from vimure_amd.tensor import SparseTensor
+    net = standard_sbm(N=N, M=N, L=L, K=K, avg_degree=3.0, eta=0.3, seed=seed, flag_self_reporter=True)
+    return SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R)
+
+
+def _engine_with_state(X, R, K, seed, mutuality=True):
+    from bench import draw_state
+    from vimure_amd import CaviEngine
+    eng = CaviEngine.from_coo(X.subs, X.vals, X.shape, R=R.subs, K=K, mutuality=mutuality)
+    sum_x, cov = eng.data_stats()
+    host, pr = draw_state(dict(L=int(X.shape[0]), N=int(X.shape[1]), M=int(X.shape[3]), K=K, mutuality=mutuality), seed, sum_x, cov)
+    eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+    eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+    return eng
+
+
+@pytest.mark.parametrize("K,mutuality", [(2, True), (3, True), (2, False)])
+def test_lockstep_loop_equals_the_single_loops(K, mutuality):
+    from vimure_amd import CaviEngine
+    sizes = [40, 64, 90, 64, 33]
+    data = [_village(N, s, K=K) for s, N in enumerate(sizes)]
+    single, states = [], []
+    for s, (X, R) in enumerate(data):
+        eng = _engine_with_state(X, R, K, 10 + s, mutuality)
+        single.append(eng.fit_loop(41, 0.1, 1))
+        states.append(eng.get_state(rho=True))
+        eng.close()
+    engs = [_engine_with_state(X, R, K, 10 + s, mutuality) for s, (X, R) in enumerate(data)]
+    both = CaviEngine.fit_loop_batch(engs, 41, 0.1, 1)
+    for s, (eng, one, two) in enumerate(zip(engs, single, both)):
+        assert [r[0] for r in one[0]] == [r[0] for r in two[0]] and one[2] == two[2] and one[3] == two[3], s
+        np.testing.assert_allclose([r[1] for r in two[0]], [r[1] for r in one[0]], rtol=1e-10)
+        assert abs(one[1] - two[1]) <= 1e-10 * abs(one[1])
+        st = eng.get_state(rho=True)
+        for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "rho"):
+            np.testing.assert_allclose(st[k], states[s][k], rtol=1e-9, atol=1e-12, err_msg=f"{s} {k}")
+        eng.close()
+
+
+def test_lockstep_with_a_handle_of_another_kind_and_early_convergence():
+    """A K = 3 handle among K = 2 ones runs its own loop; a tolerance that stops some fits early takes them out of the launch."""
+    from vimure_amd import CaviEngine
+    data = [(_village(50, 1), 2), (_village(48, 2, K=3), 3), (_village(70, 3), 2), (_village(36, 4), 2)]
+    single = []
+    for s, ((X, R), K) in enumerate(data):
+        eng = _engine_with_state(X, R, K, 20 + s)
+        single.append(eng.fit_loop(101, 5.0, 0))
+        eng.close()
+    engs = [_engine_with_state(X, R, K, 20 + s) for s, ((X, R), K) in enumerate(data)]
+    both = CaviEngine.fit_loop_batch(engs, 101, 5.0, 0)
+    assert len({r[2] for r in single}) > 1   # (the fits stop at different iterations)
+    for one, two, eng in zip(single, both, engs):
+        assert one[2] == two[2] and one[3] == two[3]
+        assert abs(one[1] - two[1]) <= 1e-10 * abs(one[1])
+        eng.close()
+
+
+def test_fit_datasets_lockstep_equals_threads():
+    from vimure_amd.batch import fit_datasets
+    data = {f"v{i}": _village(N, i, L=2) for i, N in enumerate([40, 56])}
+    a = fit_datasets(data, K=2, seeds=[1, 2], num_realisations=2, max_iter=31, lockstep=True)
+    b = fit_datasets(data, K=2, seeds=[1, 2], num_realisations=2, max_iter=31, lockstep=False, workers=1)
+    assert a[["dataset", "layer", "seed", "iters"]].values.tolist() == b[["dataset", "layer", "seed", "iters"]].values.tolist()
+    np.testing.assert_allclose(a["elbo"].values, b["elbo"].values, rtol=1e-10)
+    np.testing.assert_allclose(a["nu"].values, b["nu"].values, rtol=1e-9)

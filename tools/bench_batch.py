@@ -28,6 +28,9 @@ def main():
     t0 = time.perf_counter()
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     procs = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    if not procs:   # first use of the GPU in this process: kernel load, allocator
+        fit_datasets({"w": data["vil0"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=workers)
+        t0 = time.perf_counter()
     if procs:   # warm the worker processes up (interpreter start, imports, first kernel load): a pool serves many calls
         fit_datasets({f"w{i}": data["vil0"] for i in range(2 * procs * workers)}, K=2, seeds=range(2), num_realisations=1, max_iter=11,
                      workers=workers, processes=procs)

@@ -34,6 +34,8 @@ SIGNATURES = {
     "vmr_elbo": (C.c_int, [C.c_void_p, _dp]),
     "vmr_fit_loop": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vmr_fit_loop_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vmr_sub_step": (C.c_int, [C.c_void_p, C.c_int]),
     "vmr_sweep_local": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_commit_nu": (C.c_int, [C.c_void_p, C.c_double]),

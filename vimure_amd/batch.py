@@ -33,14 +33,7 @@ def _fit_unit(Xl, Rl, K, seeds, mutuality, device, name, keep, fit_kwargs):
     """All seeds of one (dataset, layer) unit on one engine.  Returns (rows, models or best model)."""
     rows, models = [], []
     eps = float(fit_kwargs.get("EPS", 1e-12))
-    if is_sparse_like(Xl):   # coordinate lists go to the device as they are (vmr_create_coo)
-        if Rl is not None and not is_sparse_like(Rl):
-            from .tensor import SparseTensor
-            Rl = SparseTensor.fromarray(np.asarray(Rl) != 0)
-        eng = CaviEngine.from_coo(Xl.subs, Xl.vals, Xl.shape, R=None if Rl is None else Rl.subs, K=K, mutuality=mutuality,
-                                  eps=eps, device=device)
-    else:
-        eng = CaviEngine(Xl, Rl, K=K, mutuality=mutuality, eps=eps, device=device)
+    eng = _make_engine(Xl, Rl, K, mutuality, device, eps)
     try:
         for seed in seeds:
             t0 = time.perf_counter()
@@ -60,6 +53,141 @@ def _fit_unit(Xl, Rl, K, seeds, mutuality, device, name, keep, fit_kwargs):
     finally:
         eng.close()
     return rows, models
+
+
+def _make_engine(Xl, Rl, K, mutuality, device, eps):
+    if is_sparse_like(Xl):   # coordinate lists go to the device as they are (vmr_create_coo)
+        if Rl is not None and not is_sparse_like(Rl):
+            from .tensor import SparseTensor
+            Rl = SparseTensor.fromarray(np.asarray(Rl) != 0)
+        return CaviEngine.from_coo(Xl.subs, Xl.vals, Xl.shape, R=None if Rl is None else Rl.subs, K=K, mutuality=mutuality,
+                                   eps=eps, device=device)
+    return CaviEngine(Xl, Rl, K=K, mutuality=mutuality, eps=eps, device=device)
+
+
+class _LockstepFit:
+    """One `VimureModel.fit` taken apart so that the realisations of many fits can advance together: what `fit` does before its
+    loop (`__init__`), per realisation before (`begin`) and after (`end`) the CAVI loop, and at the end (`finish`) -- the loop
+    itself runs for all fits at once (CaviEngine.fit_loop_batch).  Same draws, same bookkeeping, same results as `fit`."""
+
+    def __init__(self, Xl, Rl, K, seed, mutuality, eng, fit_kwargs, need_rho=True):
+        self.need_rho = need_rho   # False: nobody will read rho_f (table rows only): no snapshot of the best realisation, no copy
+        kw = dict(fit_kwargs)
+        pri = {k: kw.pop(k) for k in ("theta_prior", "lambda_prior", "eta_prior", "rho_prior") if k in kw}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = VimureModel(mutuality=mutuality)
+            m._check_fit_params(Xl, pri.get("lambda_prior", (10.0, 10.0)), pri.get("theta_prior", (0.1, 0.1)),
+                                pri.get("eta_prior", (0.5, 1.0)), pri.get("rho_prior"), int(seed), R=Rl, K=K, engine=eng, **kw)
+        if (eng.L, eng.N, eng.M, eng.K, eng.mutuality) != (m.L, m.N, m.M, m.K, bool(m.mutuality)):
+            raise ValueError("engine does not match the shape / K / mutuality of this fit")
+        m.close()
+        m._engine, m._rho_f = None, None
+        m.sumX, coverage = eng.data_stats()
+        eng.set_priors(m.alpha_theta, m.beta_theta, m.alpha_lambda, m.beta_lambda, m.alpha_mutuality, m.beta_mutuality)
+        m.loop_seconds = m.draw_seconds = 0.0
+        self.m, self.eng, self.seed0 = m, eng, int(seed)
+        self.states = m._initial_states(eng, coverage)
+        self.maxL, self.trace, self.best, self.final_seed = -1e10, [], None, m.seed
+        self.r = self.seed_r = None
+
+    def draw(self):
+        """Draws the next realisation's initial state on the host (into the engine's staging buffer); False when there is none
+        left.  May run while the previous realisation's loop is on the GPU: it touches no device state."""
+        t0 = time.perf_counter()
+        self._item = next(self.states, None)
+        self.m.draw_seconds += time.perf_counter() - t0
+        return self._item is not None
+
+    def upload(self):
+        """The drawn state to the device (vmr_set_state; synchronises, so the staging buffer is free again afterwards)."""
+        self.r, self.seed_r, st, self.final_seed = self._item
+        self.eng.set_state(st["gamma_shp"], st["gamma_rte"], st["phi_shp"], st["phi_rte"], st["nu_shp"], st["nu_rte"], st["pr_rho"])
+
+    def end(self, rows, elbo):
+        m = self.m
+        self.trace.extend((self.r, self.seed_r, it_, e_, rt_, rc_) for it_, e_, rt_, rc_ in rows)
+        m._pull_params(self.eng)
+        if self.maxL < elbo:
+            self.maxL, self.best = elbo, m._params_copy()
+            if m.num_realisations > 1 and self.need_rho:
+                self.eng.snapshot()
+
+    def finish(self):
+        m = self.m
+        if self.best is not None:
+            if m.num_realisations > 1 and self.need_rho:
+                self.eng.restore()
+            m._update_optimal_parameters(self.best, self.eng, lazy_rho=not self.need_rho)
+        m._change_seed(self.final_seed)
+        m.trace = pd.DataFrame(self.trace, columns=["realisation", "seed", "iter", "elbo", "runtime", "reached_convergence"])
+        m.maxL = self.maxL
+        return m
+
+
+def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=DEFAULT_WORKERS, keep=None, width=64):
+    """units: [(tag, Xl, Rl)].  Every (unit, seed) fit as `_fit_unit` would run it, but up to `width` units advance together: one
+    engine per unit holds its data, the seeds go one after the other, and realisation r of the current seed runs on all engines
+    in lockstep (vmr_fit_loop_batch: one launch per kernel and sweep for all of them).  The host's share -- the RandomState draw
+    of each initial state and its upload -- runs on `workers` threads.  Returns {tag: (rows, models)} as `_fit_unit`.
+    `seconds` of a row is the wall time of its group's pass over that seed divided by the fits in it."""
+    eps = float(fit_kwargs.get("EPS", 1e-12))
+    seeds = [int(s) for s in seeds]
+    out = {}
+    clock = {"engines": 0.0, "prepare": 0.0, "draw+upload": 0.0, "loops": 0.0, "pull": 0.0, "finish": 0.0}   # (VMR_BATCH_TIMING=1 prints it)
+
+    def timed(key, fn):
+        t = time.perf_counter()
+        r = fn()
+        clock[key] += time.perf_counter() - t
+        return r
+    order = sorted(range(len(units)), key=lambda i: -float(units[i][1].shape[1]))   # similar sizes side by side
+    with ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="vmr-draw") as ex:
+        for g0 in range(0, len(order), max(1, width)):
+            group = [units[i] for i in order[g0:g0 + max(1, width)]]
+            engs = timed("engines", lambda: list(ex.map(lambda u: _make_engine(u[1], u[2], K, mutuality, device, eps), group)))
+            try:
+                res = {u[0]: ([], []) for u in group}
+                for seed in seeds:
+                    t0 = time.perf_counter()
+                    fits = timed("prepare", lambda: list(ex.map(lambda ue: _LockstepFit(ue[0][1], ue[0][2], K, seed, mutuality, ue[1], fit_kwargs, need_rho=keep is not None), zip(group, engs))))
+                    live = list(range(len(fits)))
+                    drawn = [ex.submit(fits[i].draw) for i in live]   # realisation 0
+                    while live:
+                        live = timed("draw+upload", lambda: [i for i, d in zip(live, drawn) if d.result()])
+                        if not live:
+                            break
+                        timed("draw+upload", lambda: list(ex.map(lambda i: fits[i].upload(), live)))
+                        drawn = [ex.submit(fits[i].draw) for i in live]   # the next realisation's draws run while this one sweeps
+                        m0 = fits[live[0]].m
+                        t1 = time.perf_counter()
+                        loops = CaviEngine.fit_loop_batch([engs[i] for i in live], m0.max_iter, m0.convergence_tol, m0.decision)
+                        dt = time.perf_counter() - t1
+                        clock["loops"] += dt
+
+                        def end(il):
+                            fits[il[0]].m.loop_seconds += dt
+                            fits[il[0]].end(il[1][0], il[1][1])
+                        timed("pull", lambda: list(ex.map(end, zip(live, loops))))
+                    models = timed("finish", lambda: list(ex.map(lambda f: f.finish(), fits)))
+                    dt = (time.perf_counter() - t0) / max(1, len(fits))
+                    for u, m in zip(group, models):
+                        rows, kept = res[u[0]]
+                        rows.append({"layer": u[0], "seed": seed, "elbo": float(m.maxL),
+                                     "iters": int(m.trace["iter"].max()) if len(m.trace) else 0,
+                                     "converged": bool(m.trace["reached_convergence"].any()) if len(m.trace) else False,
+                                     "seconds": dt, "nu": float(m.G_exp_nu_f)})
+                        if keep == "all":
+                            kept.append((seed, m, dt))
+                        elif keep == "best" and (not kept or kept[0][1].maxL < m.maxL):
+                            kept[:] = [(seed, m, dt)]
+                out.update(res)
+            finally:
+                for e in engs:
+                    e.close()
+    if os.environ.get("VMR_BATCH_TIMING"):
+        print("fit_units_lockstep seconds:", {k: round(v, 3) for k, v in clock.items()}, flush=True)
+    return out
 
 
 def _as_data(X, R):
@@ -209,12 +337,14 @@ def fit_layers(X, R=None, K=2, seeds: Iterable[int] = range(10), layer_names: Se
 
 
 def fit_datasets(datasets: Dict[str, tuple], K=2, seeds: Iterable[int] = range(10), dist=None, device=None,
-                 workers=DEFAULT_WORKERS, processes=0, **fit_kwargs) -> pd.DataFrame:
+                 workers=DEFAULT_WORKERS, processes=0, lockstep=True, **fit_kwargs) -> pd.DataFrame:
     """datasets: name -> (X, R, layer_names or None).  Units (dataset, layer) are sharded over the ranks of
     `dist` (one process per GPU), all seeds of a unit run on the rank that holds its data, units of a rank run
     concurrently on `workers` threads -- in `processes` worker processes on the rank's GPU when processes > 0 (keep
     processes x ranks per GPU small: a handful); the per-fit rows are gathered on every rank (RCCL / gloo all_gather of
-    [unit, seed, elbo, iters, seconds, nu])."""
+    [unit, seed, elbo, iters, seconds, nu]).  lockstep (the default without worker processes): the units of a rank advance
+    together, every sweep one launch per kernel for all of them (`fit_units_lockstep`); lockstep=False: one engine and stream
+    per host thread, as before."""
     from .multifit import partition
     seeds = list(seeds)
     units = []
@@ -241,7 +371,10 @@ def fit_datasets(datasets: Dict[str, tuple], K=2, seeds: Iterable[int] = range(1
         return rows
     # longest units first: the tail of the schedule is short fits
     order = sorted(mine, key=lambda ui: -units[ui][2])
-    if processes > 0:
+    if processes <= 0 and lockstep and len(order) > 1:
+        by_tag = fit_units_lockstep([(ui,) + tuple(data_of(ui)) for ui in order], K, seeds, mutuality, device, fit_kwargs, workers=workers)
+        res = [(ui, by_tag[ui][0]) for ui in order]
+    elif processes > 0:
         by_tag = _run_units_processes([(ui,) + tuple(data_of(ui)) for ui in order], K, seeds, mutuality, device, processes, workers,
                                       fit_kwargs)
         res = [(ui, by_tag[ui]) for ui in order]

@@ -156,6 +156,15 @@ int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long l
 // ------------------------------------------------------------------------------------------
 #define SL_DECL(K_) __attribute__((weak)) int vmr_sl_launch_k##K_(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a);
 SL_DECL(2) SL_DECL(3) SL_DECL(4) SL_DECL(5) SL_DECL(6) SL_DECL(7) SL_DECL(8)
+#define SL_DECLB(K_) __attribute__((weak)) int vmr_sl_launch_batch_k##K_(vmr_ctx* h, hipStream_t st, int mode, int allfull, const SlUnit* units, const int* blk_unit, int nblocks, int tpb, size_t smem);
+SL_DECLB(2) SL_DECLB(3) SL_DECLB(4) SL_DECLB(5) SL_DECLB(6) SL_DECLB(7) SL_DECLB(8)
+sl_launch_batch_fn vmr_sl_batch_launcher(int K) {
+  switch (K) {
+    case 2: return vmr_sl_launch_batch_k2; case 3: return vmr_sl_launch_batch_k3; case 4: return vmr_sl_launch_batch_k4; case 5: return vmr_sl_launch_batch_k5;
+    case 6: return vmr_sl_launch_batch_k6; case 7: return vmr_sl_launch_batch_k7; case 8: return vmr_sl_launch_batch_k8;
+    default: return nullptr;
+  }
+}
 sl_launch_fn vmr_sl_launcher(int K) {
   switch (K) {
     case 2: return vmr_sl_launch_k2; case 3: return vmr_sl_launch_k3; case 4: return vmr_sl_launch_k4; case 5: return vmr_sl_launch_k5;

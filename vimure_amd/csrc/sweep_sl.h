@@ -57,6 +57,8 @@ struct SlArgs {
 };
 
 struct SlShape { int tpb, yt, hc; size_t smem; };
+// one handle's share of a launch that serves many (k_sweep_sl_b): its arguments, its first workgroup and how many it has
+struct SlUnit { SlArgs a; Geo g; int blk0, nblk; };
 
 // Register budget of a variant: the per-tie state grows with K (log prior, sums, rho, table rows: ~14 K registers) and the
 // ELBO variants carry the logarithms' on top, so the kernels are compiled for fewer, fatter waves as K grows -- no variant
@@ -80,6 +82,10 @@ static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elb
 // mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2)
 typedef int (*sl_launch_fn)(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a);
 sl_launch_fn vmr_sl_launcher(int K);   // null when K was not compiled in
+// mode 0 / 1 (rho update / + ELBO data terms) of the units' sweeps in one launch on `st`; units / blk_unit: device memory
+typedef int (*sl_launch_batch_fn)(vmr_ctx* h, hipStream_t st, int mode, int allfull, const SlUnit* units, const int* blk_unit, int nblocks,
+                                  int tpb, size_t smem);
+sl_launch_batch_fn vmr_sl_batch_launcher(int K);
 
 // sorted_lists.hip
 // Builds perm, rs, E (and ebase, n_slots) from tie-major entries.  rp [L][T+1]: per-tie report counts (overwritten by their

@@ -58,8 +58,10 @@ __device__ __forceinline__ double rcp_nr2(double d) {
 #endif
 template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 : (K <= 4 ? 4 : 2); };
 
+// The sweep over one handle's lists.  bx / gx: this workgroup's index in, and the size of, the handle's grid -- the whole launch
+// (k_sweep_sl) or a handle's share of a launch that serves many small handles (k_sweep_sl_b).
 template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
-__global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL, UPDATE)) void k_sweep_sl(SlArgs a, Geo g) {
+__device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const unsigned bx, const unsigned gx) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
@@ -80,9 +82,9 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !E
   double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;
   double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
+  const int l = (int)bx / a.Gl, gb = (int)bx - l * a.Gl;
 #ifdef SL_DEBUG
-  unsigned long long* dbt = a.dbg_t ? a.dbg_t + ((size_t)blockIdx.x * nw + wv) * 4 : nullptr;
+  unsigned long long* dbt = a.dbg_t ? a.dbg_t + ((size_t)bx * nw + wv) * 4 : nullptr;
   if (dbt && lane == 0) dbt[0] = wall_clock64();
 #endif
   const size_t T = (size_t)g.N * g.N;
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !E
     if (tid == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's share is performed at the memory side before the ticket is drawn)
       const double t = atomicAdd(&a.nu_acc[1], 1.0);
-      nu_last = (t == (double)(gridDim.x - 1));
+      nu_last = (t == (double)(gx - 1u));
       if (nu_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -729,13 +731,28 @@ __global__ __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !E
     double v2 = block_sum_n(e_log, red);
     double v3 = block_sum_n(e_q, red);
     if (tid == 0) {
-      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+      double* out = a.slotR + (size_t)(bx % NSLOT) * 4;
       atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
     }
   }
 #ifdef SL_DEBUG
   if (dbt && lane == 0) dbt[3] = wall_clock64();
 #endif
+}
+
+#define SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) \
+  __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL, UPDATE))
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+__global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl(SlArgs a, Geo g) {
+  sweep_body<K, UPDATE, ELBO, ALLFULL>(a, g, blockIdx.x, gridDim.x);
+}
+// One launch for many small handles in lockstep (vmr_fit_loop_batch): workgroup -> unit through `blk_unit`, the unit's
+// arguments from device memory.  A sweep of a Karnataka-sized layer is two dependent 20-40 us launches that leave the GPU
+// nearly empty; here every unit's sweep shares them.
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+__global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl_b(const SlUnit* __restrict__ units, const int* __restrict__ blk_unit) {
+  const SlUnit& u = units[blk_unit[blockIdx.x]];
+  sweep_body<K, UPDATE, ELBO, ALLFULL>(u.a, u.g, blockIdx.x - (unsigned)u.blk0, (unsigned)u.nblk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,4 +809,24 @@ int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlAr
     case 2: return sl_launch_one<false, true, false>(h, sh, a);
     default: return sl_launch_one<false, false, false>(h, sh, a);
   }
+}
+
+// the rho update (mode 0) or rho update + ELBO data terms (mode 1) of `nblocks` workgroups' worth of units in one launch
+template <bool ELBO, bool ALLFULL>
+static int sl_launch_batch_one(vmr_ctx* h, hipStream_t st, const SlUnit* units, const int* blk_unit, int nblocks, int tpb, size_t smem) {
+  constexpr int K = VMR_K;
+  static size_t attr = 48 * 1024;   // (largest dynamic LDS size this kernel has been given leave for)
+  if (smem > attr) {
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, true, ELBO, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = smem;
+  }
+  hipLaunchKernelGGL((k_sweep_sl_b<K, true, ELBO, ALLFULL>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
+  return VMR_OK;
+}
+int SL_CAT(vmr_sl_launch_batch_k, VMR_K)(vmr_ctx* h, hipStream_t st, int mode, int allfull, const SlUnit* units, const int* blk_unit, int nblocks,
+                                          int tpb, size_t smem) {
+  if (allfull) return mode ? sl_launch_batch_one<true, true>(h, st, units, blk_unit, nblocks, tpb, smem)
+                           : sl_launch_batch_one<false, true>(h, st, units, blk_unit, nblocks, tpb, smem);
+  return mode ? sl_launch_batch_one<true, false>(h, st, units, blk_unit, nblocks, tpb, smem)
+              : sl_launch_batch_one<false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
 }

@@ -1977,16 +1977,18 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
 // layer's last ticket finishes lambda and builds F and the LUT from the theta values the others published (release before
 // the ticket, acquire after it).  One workgroup per layer (rounds 1-2) kept 4 of 256 CUs busy for 25 us per sweep.
 // consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for the rho pass.
-__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
-                                                       double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
-                                                       int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, Geo g) {
+// (bx: the workgroup's index in its handle's grid -- the launch's, or the handle's share of a lockstep launch, k_fin_gamma_b)
+__device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
+                                               double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
+                                               int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, const Geo& g,
+                                               const int bx) {
   extern __shared__ double dyn[];   // s1[mper]: sum_{y,k} w1 H per reporter; gthn[mper]: the new G_theta
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   __shared__ double lla_n[KMAX], gla_n[KMAX];   // the new E[log lambda], G_lambda (for the factor table F)
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / FG_G, gq = blockIdx.x - l * FG_G, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
+  const int l = bx / FG_G, gq = bx - l * FG_G, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
   const int mper = (g.M + FG_G - 1) / FG_G, m0 = gq * mper, m1 = min(g.M, m0 + mper), nm = max(0, m1 - m0);
   double* s1 = dyn;
   double* gthn = dyn + mper;
@@ -2187,6 +2189,19 @@ __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, 
     if (tid == 0) nu_acc[2 + l] = c0;
   }
 }
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
+                                                       double* lutg, double* Fg, double* fin, double* nu_acc, int nh, int do_phi, int consume, Geo g) {
+  fin_gamma_body(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x);
+}
+// the finalize kernels of many small handles in one launch (vmr_fit_loop_batch): workgroup -> unit through blk_unit
+struct FinUnit {
+  double *par, *Hg; const double* Cg; double *slotA, *slotF, *lutg, *fin_g, *nu_acc, *slotR, *elbo;   // (elbo: 8 doubles, as vmr_ctx::elbo_dev)
+  Geo g; int fg_blk0, fr_blk0, fr_nblk;
+};
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit) {
+  const FinUnit& u = units[blk_unit[blockIdx.x]];
+  fin_gamma_body(u.par, u.Hg, u.Cg, u.slotA, u.slotF, u.lutg, nullptr, u.fin_g, u.nu_acc, NH, 1, 1, u.g, (int)blockIdx.x - u.fg_blk0);
+}
 
 // phi commit, mutuality on: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887; the cache
 // refresh of :647 sits between the two updates), phi_rte as computed by k_fin_gamma (model.py:742-749)
@@ -2228,13 +2243,14 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 // One workgroup per layer adds its share to fin[0..1] with device-scope atomics; the workgroup that draws the
 // last ticket (fin[2]) finishes the scalars and clears the scratch.
 #define FR_G 16   // workgroups per layer of k_fin_rho
-__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
-                                                 double* fin, int do_nu, int do_elbo, int fold, int skip_nu /* the pass finished nu itself */, Geo g) {
+__device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
+                                             double* fin, int do_nu, int do_elbo, int fold, int skip_nu /* the pass finished nu itself */, const Geo& g,
+                                             const int bx, const int gx) {
   __shared__ double red[8];
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
   double* sc = par + o.sc;
-  const int l = blockIdx.x / FR_G, gs = blockIdx.x - l * FR_G;
+  const int l = bx / FR_G, gs = bx - l * FR_G;
   double a0 = 0.0, gt = 0.0;
   if (!skip_nu && (g.mut || fold)) {   // threads take (y, m) items of H; fold: the NH copies are summed into copy 0 on the way
     const double gnu = sc[SC_G_NU];
@@ -2275,7 +2291,7 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const 
     // __threadfence() -- L2 write-back and invalidate, ~3.5 us -- orders plain stores, of which the ticket publishes none)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double t = atomicAdd(&fin[2], 1.0);
-    last = (t == (double)(gridDim.x - 1));
+    last = (t == (double)(gx - 1));
   }
   __syncthreads();
   if (!last) return;
@@ -2306,6 +2322,15 @@ __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const 
     elbo_out[2] = a1 + a2 + gt;   // local ELBO terms that do not involve nu
     elbo_out[3] = a3;             // local sum_t (sum_k rho) Q_t, enters the ELBO as -E[nu] * (.)
   }
+}
+__global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
+                                                 double* fin, int do_nu, int do_elbo, int fold, int skip_nu, Geo g) {
+  fin_rho_body(par, Hg, Cg, slotR, elbo_out, fin, do_nu, do_elbo, fold, skip_nu, g, (int)blockIdx.x, (int)gridDim.x);
+}
+// (lockstep launch: the ELBO of a sweep whose pass finished nu itself)
+__global__ __launch_bounds__(TPB) void k_fin_rho_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit) {
+  const FinUnit& u = units[blk_unit[blockIdx.x]];
+  fin_rho_body(u.par, u.Hg, u.Cg, u.slotR, u.elbo, u.elbo + 4, 0, 1, 0, 1, u.g, (int)blockIdx.x - u.fr_blk0, u.fr_nblk);
 }
 
 // commit a nu_shp that was summed over several handles (layer-sharded fits)
@@ -2934,9 +2959,11 @@ static int mask_lists_from_words(vmr_ctx* h) {
   bool ok32 = true;
   h->n_rm = 0;
   for (int l = 0; l < L; ++l) { rb_[l] = h->n_rm; h->n_rm += rl_[l]; ok32 = ok32 && rl_[l] < 0xffffffffull; }
-  // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row)
+  // worth it when a list row is at most a quarter of the row's mask words (and rows are short: one lane walks a row) -- and
+  // for small networks whatever the bytes: the sweep's pass sums the lists on its way, a launch less per sweep where the
+  // launches are what a sweep costs
   const double list_bytes = 2.0 * (double)h->n_rm + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
-  if (ok32 && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024) {   // (A[Mp][K] of k_mask_lists lives in LDS)
+  if (ok32 && maxrow <= 64 && (list_bytes * 4.0 <= word_bytes || g.N <= 1024) && (size_t)g.Mp * K * 8 <= 160 * 1024) {   // (A[Mp][K] of k_mask_lists lives in LDS)
     for (int l = 0; l < L; ++l) { int rc = scan_u32(h, h->rq + (size_t)l * n, bsum, n); if (rc) return rc; }
     CK(hipMalloc(&h->rbase, (size_t)L * 8));
     CK(hipMemcpyAsync(h->rbase, rb_.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
@@ -3028,7 +3055,7 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     };
     int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
     bool one = best(true, true, 16, lv1, t1);
-    if (one && lv1 < want) {
+    if (one && lv1 < want && g.N > 1024) {   // (small networks: one pass whatever the levels -- a sweep there costs its launches)
       // Not every level fits beside the other table.  A report of a level beyond the LDS ones costs its whole 64-tie round the
       // slow path (the factor formula, a global add), so one pass only pays while such reports are rare: count the reports
       // per level.  (BASELINE config 5 -- M = 1000, K = 3: 3 levels of each fit, 2.5 % of the reports lie beyond, four rounds
@@ -3502,7 +3529,7 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   // the mask: all ones needs nothing; partial rows become mask lists when they are short, bit-packed words otherwise
   if (nr >= 0 && h->n_partial > 0) {
     const double list_bytes = 2.0 * (double)nr + 4.0 * (double)rows, word_bytes = (double)h->n_partial * g.W * 8.0;
-    const bool lists = !getenv("VMR_NO_RLISTS") && maxrow <= 64 && list_bytes * 4.0 <= word_bytes && (size_t)g.Mp * K * 8 <= 160 * 1024;
+    const bool lists = !getenv("VMR_NO_RLISTS") && maxrow <= 64 && (list_bytes * 4.0 <= word_bytes || g.N <= 1024) && (size_t)g.Mp * K * 8 <= 160 * 1024;
     if (lists) {
       unsigned* bs = nullptr;
       CKC(hipMalloc(&h->rq, n1 * 4));
@@ -3740,38 +3767,258 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
 }
 
 // the convergence loop of `fit` for one realisation (model.py:405-426, 1021-1056), without a host-language round trip
-// per iteration: one call per realisation, so several fits driven from host threads do not queue for an interpreter lock
+// per iteration: one call per realisation, so several fits driven from host threads do not queue for an interpreter lock.
+// (st: where the loop stands -- a fresh realisation, or one whose first iterations ran elsewhere, see vmr_fit_loop_batch)
+struct LoopState { int it = 1, coincide = 0, reached = 0, rows = 0; double elbo = -1e10; /* INF of the reference (model.py:24) */ };
+static int fit_loop_core(vmr_ctx* h, LoopState& st, int max_iter, double tol, int decision, int cap, int* row_iter, double* row_elbo,
+                         double* row_runtime, int* row_reached) {
+  int rc;
+  while (!st.reached && st.it <= max_iter) {
+    // the ELBO is evaluated at iteration 1, every 10th and the last (model.py:1036-1039); the sweeps in between are queued at once
+    const int it = st.it;
+    const int nxt = (it == 1 || it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
+    if (nxt > it) {
+      if ((rc = vmr_step(h, nxt - it, nullptr))) return rc;
+      st.it = nxt;
+      HIPCHK(h, hipStreamSynchronize(h->stream));   // so that the runtime below is this iteration's sweep, as in the reference
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const double old = st.elbo;
+    if ((rc = vmr_step(h, 1, &st.elbo))) return rc;
+    const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    st.coincide = (fabs(st.elbo - old) < tol) ? st.coincide + 1 : 0;
+    if (st.coincide > decision) st.reached = 1;
+    ++st.it;
+    if ((st.it - 1) % 10 == 0 && st.rows < cap) {
+      row_iter[st.rows] = st.it - 1; row_elbo[st.rows] = st.elbo; row_runtime[st.rows] = runtime; row_reached[st.rows] = st.reached;
+      ++st.rows;
+    }
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return VMR_OK;
+}
 int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter, double* row_elbo,
                  double* row_runtime, int* row_reached, double* elbo_out, int* iters_out, int* converged_out) {
   if (!h || !n_rows || !elbo_out || !iters_out || !converged_out) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_fit_loop");
   if (h->restored) return fail(h, VMR_ESTATE, "vmr_fit_loop after vmr_restore: the restored state is read-only until the next vmr_set_state");
   if (cap > 0 && (!row_iter || !row_elbo || !row_runtime || !row_reached)) return fail(h, VMR_EINVAL, "trace arrays missing");
-  int coincide = 0, it = 1, reached = 0, rows = 0, rc;
-  double elbo = -1e10;   // INF of the reference (model.py:24)
-  while (!reached && it <= max_iter) {
-    // the ELBO is evaluated at iteration 1, every 10th and the last (model.py:1036-1039); the sweeps in between are queued at once
-    const int nxt = (it == 1 || it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
-    if (nxt > it) {
-      if ((rc = vmr_step(h, nxt - it, nullptr))) return rc;
-      it = nxt;
-      HIPCHK(h, hipStreamSynchronize(h->stream));   // so that the runtime below is this iteration's sweep, as in the reference
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    const double old = elbo;
-    if ((rc = vmr_step(h, 1, &elbo))) return rc;
-    const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    coincide = (fabs(elbo - old) < tol) ? coincide + 1 : 0;
-    if (coincide > decision) reached = 1;
-    ++it;
-    if ((it - 1) % 10 == 0 && rows < cap) {
-      row_iter[rows] = it - 1; row_elbo[rows] = elbo; row_runtime[rows] = runtime; row_reached[rows] = reached;
-      ++rows;
-    }
-  }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  *n_rows = rows; *elbo_out = elbo; *iters_out = it - 1; *converged_out = reached;
+  LoopState st;
+  int rc = fit_loop_core(h, st, max_iter, tol, decision, cap, row_iter, row_elbo, row_runtime, row_reached);
+  if (rc) return rc;
+  *n_rows = st.rows; *elbo_out = st.elbo; *iters_out = st.it - 1; *converged_out = st.reached;
   return VMR_OK;
+}
+
+// ---- many small fits in lockstep -----------------------------------------------------------------------------------
+// A sweep of a Karnataka-sized layer (N = 200-800, L = 1) is two dependent launches of 20-40 us each that leave the GPU nearly
+// empty, and launches of different streams of one process hardly overlap (8 host threads: 1.4x one thread's sweeps per
+// second).  Here the realisations of n handles advance together: every sweep is ONE launch of the finalize kernel and ONE of
+// the pass for all of them (k_fin_gamma_b, k_sweep_sl_b; on ELBO sweeps k_fin_rho_b and one copy of n ELBOs), each handle's
+// workgroups reading its own arguments from a table in device memory.  A handle that converges leaves the tables.
+// Handles of another kind than the first (K, mutuality, mask kind, report lists in one pass) run their loops one by one.
+static bool batch_steady(const vmr_ctx* h) {
+  const Geo& g = h->g;
+  return h->have_state && !h->restored && h->sparse && h->sl && !g.two_pass && h->h_valid && !h->h_reduced && !h->h_zero &&
+         h->f_valid == (g.fuse_full != 0) && (!g.ml || h->a_valid) && !h->prof;
+}
+static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
+  // (a sweep of such a handle is k_fin_gamma + the pass, + k_fin_rho with an ELBO: the pass sums rho over the mask itself)
+  return h->sparse && h->sl && !h->g.two_pass && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
+         h->g.K == h0->g.K && h->g.mut == h0->g.mut && (h->all_full != 0) == (h0->all_full != 0);
+}
+namespace {
+struct BatchTables {   // device copies of the unit tables of one lockstep loop
+  SlUnit* su[2] = {nullptr, nullptr};   // mode 0 / 1
+  int* smap[2] = {nullptr, nullptr};
+  FinUnit* fu = nullptr;
+  int *gmap = nullptr, *rmap = nullptr;
+  double* be = nullptr;                 // [n][8]: every unit's elbo_dev
+  int nb[2] = {0, 0}, ngb = 0, nrb = 0, tpb[2] = {0, 0};
+  size_t smem[2] = {0, 0}, fsm = 0;
+  ~BatchTables() { for (void* p : {(void*)su[0], (void*)su[1], (void*)smap[0], (void*)smap[1], (void*)fu, (void*)gmap, (void*)rmap, (void*)be}) if (p) (void)hipFree(p); }
+};
+}  // namespace
+// (re)builds the tables for the units listed in `act`
+static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_all, BatchTables& bt, hipStream_t st) {
+  vmr_ctx* h0 = hs[act[0]];
+  const int K = h0->g.K, allfull = h0->all_full != 0;
+  long long steps = 0;
+  for (int u : act) steps += (((long long)hs[u]->g.N * hs[u]->g.N + 63) / 64) * hs[u]->g.L;
+  std::vector<FinUnit> fu(act.size());
+  std::vector<int> gmap, rmap;
+  for (int m = 0; m < 2; ++m) {
+    const int tpb = sl_tpb_max(K, m == 1, allfull, true), nw = tpb / 64;
+    // steps per wave: about one workgroup per CU in all (the tables in LDS allow few more, and a second round of workgroups
+    // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each
+    const long long per = std::max<long long>(4, std::min<long long>(64, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
+    std::vector<SlUnit> su(act.size());
+    std::vector<int> map;
+    size_t smem = 0;
+    for (size_t i = 0; i < act.size(); ++i) {
+      vmr_ctx* h = hs[act[i]];
+      const Geo& g = h->g;
+      const SlShape sh = sl_shape(h, true, m == 1, true);
+      SlArgs a = sl_args(h, sh, 1, g.ml ? 1 : 0);
+      a.elbo_dev = bt.be + (size_t)act[i] * 8;
+      if (g.mut) { a.nu_acc = h->nu_acc; a.commit_nu = 1; }
+      const long long NS = ((long long)g.N * g.N + 63) / 64;
+      a.Gl = (int)std::max<long long>(1, std::min<long long>(4096, (NS + nw * per - 1) / (nw * per)));
+      su[i].a = a; su[i].g = g; su[i].blk0 = (int)map.size(); su[i].nblk = g.L * a.Gl;
+      map.insert(map.end(), (size_t)su[i].nblk, (int)i);
+      smem = std::max(smem, sh.smem);
+    }
+    HIPCHK(h0, hipMemcpyAsync(bt.su[m], su.data(), su.size() * sizeof(SlUnit), hipMemcpyHostToDevice, st));
+    HIPCHK(h0, hipMemcpyAsync(bt.smap[m], map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(h0, hipStreamSynchronize(st));   // (the host vectors go away)
+    bt.nb[m] = (int)map.size(); bt.tpb[m] = tpb; bt.smem[m] = smem;
+  }
+  bt.fsm = 0;
+  for (size_t i = 0; i < act.size(); ++i) {
+    vmr_ctx* h = hs[act[i]];
+    const Geo& g = h->g;
+    fu[i] = FinUnit{h->par, h->Hg, h->Cg, h->slotA, h->slotF, h->lutg, h->fin_g, h->nu_acc, h->slotR, bt.be + (size_t)act[i] * 8, g,
+                    (int)gmap.size(), (int)rmap.size(), g.L * FR_G};
+    gmap.insert(gmap.end(), (size_t)g.L * FG_G, (int)i);
+    rmap.insert(rmap.end(), (size_t)g.L * FR_G, (int)i);
+    bt.fsm = std::max(bt.fsm, (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8);
+  }
+  HIPCHK(h0, hipMemcpyAsync(bt.fu, fu.data(), fu.size() * sizeof(FinUnit), hipMemcpyHostToDevice, st));
+  HIPCHK(h0, hipMemcpyAsync(bt.gmap, gmap.data(), gmap.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(h0, hipMemcpyAsync(bt.rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(h0, hipStreamSynchronize(st));
+  bt.ngb = (int)gmap.size(); bt.nrb = (int)rmap.size();
+  (void)n_all;
+  return VMR_OK;
+}
+
+int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int decision, int cap, int* n_rows, int* row_iter, double* row_elbo,
+                       double* row_runtime, int* row_reached, double* elbo_out, int* iters_out, int* converged_out, int* rc_out) {
+  if (!hs || n <= 0 || !n_rows || !elbo_out || !iters_out || !converged_out || !rc_out) return VMR_EINVAL;
+  if (cap > 0 && (!row_iter || !row_elbo || !row_runtime || !row_reached)) return VMR_EINVAL;
+  for (int u = 0; u < n; ++u) {
+    if (!hs[u]) return VMR_EINVAL;
+    for (int v = 0; v < u; ++v) if (hs[v] == hs[u]) return fail(hs[u], VMR_EINVAL, "vmr_fit_loop_batch: a handle is listed twice");
+    rc_out[u] = VMR_OK;
+  }
+  std::vector<LoopState> ls(n);
+  auto rows_of = [&](int u, int*& ri, double*& re, double*& rr, int*& rq) {
+    ri = cap > 0 ? row_iter + (size_t)u * cap : nullptr; re = cap > 0 ? row_elbo + (size_t)u * cap : nullptr;
+    rr = cap > 0 ? row_runtime + (size_t)u * cap : nullptr; rq = cap > 0 ? row_reached + (size_t)u * cap : nullptr;
+  };
+  auto solo = [&](int u) {   // this unit's loop (or the rest of it) on its own
+    int* ri; double* re; double* rr; int* rq;
+    rows_of(u, ri, re, rr, rq);
+    vmr_ctx* h = hs[u];
+    if (!h->have_state) { rc_out[u] = fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_fit_loop_batch"); return; }
+    if (h->restored) { rc_out[u] = fail(h, VMR_ESTATE, "vmr_fit_loop_batch after vmr_restore: the restored state is read-only until the next vmr_set_state"); return; }
+    rc_out[u] = fit_loop_core(h, ls[u], max_iter, tol, decision, cap, ri, re, rr, rq);
+  };
+  auto finish = [&]() {
+    int worst = VMR_OK;
+    for (int u = 0; u < n; ++u) {
+      n_rows[u] = ls[u].rows; elbo_out[u] = ls[u].elbo; iters_out[u] = ls[u].it - 1; converged_out[u] = ls[u].reached;
+      if (rc_out[u] && !worst) worst = rc_out[u];
+    }
+    return worst;
+  };
+  // the units of the first batchable handle's kind advance together; the others run alone
+  int lead = -1;
+  for (int u = 0; u < n && lead < 0; ++u) if (hs[u]->have_state && !hs[u]->restored && batch_kind(hs[u], hs[u])) lead = u;
+  std::vector<int> act;
+  for (int u = 0; u < n; ++u) {
+    if (lead >= 0 && hs[u]->have_state && !hs[u]->restored && batch_kind(hs[u], hs[lead]) && vmr_sl_batch_launcher(hs[u]->g.K)) act.push_back(u);
+    else solo(u);
+  }
+  if (act.size() < 2 || max_iter < 2) { for (int u : act) solo(u); return finish(); }
+  vmr_ctx* h0 = hs[act[0]];
+  HIPCHK(h0, hipSetDevice(h0->device));
+  // iteration 1 (the ELBO is evaluated there, model.py:1036) on every handle's own stream: it builds the statistics of the
+  // initial rho -- launches the steady sweeps do not have
+  for (int u : act) { rc_out[u] = sweep(hs[u], 1); }
+  for (size_t i = 0; i < act.size();) {
+    const int u = act[i];
+    if (!rc_out[u]) rc_out[u] = read_elbo(hs[u], &ls[u].elbo);
+    if (rc_out[u]) { (void)hipStreamSynchronize(hs[u]->stream); act.erase(act.begin() + i); continue; }
+    ls[u].coincide = (fabs(ls[u].elbo - (-1e10)) < tol) ? 1 : 0;
+    if (ls[u].coincide > decision) ls[u].reached = 1;
+    ls[u].it = 2;
+    if (ls[u].reached) { act.erase(act.begin() + i); continue; }
+    if (!batch_steady(hs[u])) { solo(u); act.erase(act.begin() + i); continue; }
+    ++i;
+  }
+  if (act.size() < 2) { for (int u : act) solo(u); return finish(); }
+  h0 = hs[act[0]];
+  hipStream_t st = h0->stream;
+  const int K = h0->g.K, allfull = h0->all_full != 0;
+  sl_launch_batch_fn pass = vmr_sl_batch_launcher(K);
+  BatchTables bt;
+  {
+    size_t blocks = 0, gb = 0, rb = 0;
+    for (int u : act) {
+      const Geo& g = hs[u]->g;
+      blocks += (size_t)g.L * 4096; gb += (size_t)g.L * FG_G; rb += (size_t)g.L * FR_G;
+    }
+    for (int m = 0; m < 2; ++m) {
+      HIPCHK(h0, hipMalloc(&bt.su[m], act.size() * sizeof(SlUnit)));
+      HIPCHK(h0, hipMalloc(&bt.smap[m], blocks * sizeof(int)));
+    }
+    HIPCHK(h0, hipMalloc(&bt.fu, act.size() * sizeof(FinUnit)));
+    HIPCHK(h0, hipMalloc(&bt.gmap, gb * sizeof(int)));
+    HIPCHK(h0, hipMalloc(&bt.rmap, rb * sizeof(int)));
+    HIPCHK(h0, hipMalloc(&bt.be, (size_t)n * 8 * 8));
+    HIPCHK(h0, hipMemsetAsync(bt.be, 0, (size_t)n * 8 * 8, st));
+  }
+  std::vector<double> be_host((size_t)n * 8);
+  int rc = batch_tables(hs, act, n, bt, st);
+  if (rc) return rc;
+  auto launch_sweeps = [&](int mode) -> int {
+    hipLaunchKernelGGL(k_fin_gamma_b, dim3(bt.ngb), dim3(FIN_TPB), bt.fsm, st, bt.fu, bt.gmap);
+    int r = pass(h0, st, mode, allfull, bt.su[mode], bt.smap[mode], bt.nb[mode], bt.tpb[mode], bt.smem[mode]);
+    if (r) return r;
+    if (mode == 1) hipLaunchKernelGGL(k_fin_rho_b, dim3(bt.nrb), dim3(TPB), 0, st, bt.fu, bt.rmap);
+    HIPCHK(h0, hipGetLastError());
+    return VMR_OK;
+  };
+  int it = 2;   // every active unit stands at the same iteration
+  while (!act.empty() && it <= max_iter) {
+    const int nxt = (it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
+    for (; it < nxt; ++it) if ((rc = launch_sweeps(0))) break;
+    if (rc) break;
+    HIPCHK(h0, hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = launch_sweeps(1))) break;
+    HIPCHK(h0, hipMemcpyAsync(be_host.data(), bt.be, (size_t)n * 8 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h0, hipStreamSynchronize(st));
+    const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ++it;
+    bool changed = false;
+    for (size_t i = 0; i < act.size();) {
+      const int u = act[i];
+      LoopState& s = ls[u];
+      const double old = s.elbo;
+      s.elbo = be_host[(size_t)u * 8];
+      s.it = it;
+      bool out = false;
+      if (isnan(s.elbo)) { rc_out[u] = fail(hs[u], VMR_ENAN, "ELBO is NaN!!!!"); out = true; }
+      else {
+        s.coincide = (fabs(s.elbo - old) < tol) ? s.coincide + 1 : 0;
+        if (s.coincide > decision) s.reached = 1;
+        if ((it - 1) % 10 == 0 && s.rows < cap) {
+          int* ri; double* re; double* rr; int* rq;
+          rows_of(u, ri, re, rr, rq);
+          ri[s.rows] = it - 1; re[s.rows] = s.elbo; rr[s.rows] = runtime; rq[s.rows] = s.reached;
+          ++s.rows;
+        }
+        out = s.reached != 0;
+      }
+      if (out) { act.erase(act.begin() + i); changed = true; } else ++i;
+    }
+    if (changed && !act.empty() && it <= max_iter && (rc = batch_tables(hs, act, n, bt, st))) break;
+  }
+  (void)hipStreamSynchronize(st);
+  if (rc) { for (int u : act) if (!rc_out[u]) rc_out[u] = rc; }
+  return finish();
 }
 
 int vmr_elbo(vmr_handle h, double* out) {

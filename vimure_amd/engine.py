@@ -236,6 +236,31 @@ class CaviEngine:
         k = n.value
         return list(zip(ri[:k].tolist(), re[:k].tolist(), rt[:k].tolist(), [bool(v) for v in rr[:k]])), e.value, its.value, bool(conv.value)
 
+    @staticmethod
+    def fit_loop_batch(engines, max_iter, tol, decision):
+        """`fit_loop` of several engines in lockstep (vmr_fit_loop_batch): the sweeps of all of them share one launch per kernel.
+        Every engine must have had its `set_state`.  Returns one `fit_loop` result per engine, in order."""
+        engines = list(engines)
+        n = len(engines)
+        if n == 0:
+            return []
+        lib = engines[0].lib
+        cap = max_iter // 10 + 2
+        hs = (C.c_void_p * n)(*[e._h for e in engines])
+        nr, its, conv, rcs = (np.zeros(n, np.int32) for _ in range(4))
+        e = np.zeros(n)
+        ri, rr = np.empty((n, cap), np.int32), np.empty((n, cap), np.int32)
+        re, rt = np.empty((n, cap)), np.empty((n, cap))
+        lib.vmr_fit_loop_batch(hs, n, int(max_iter), float(tol), int(decision), cap, nr.ctypes.data, ri.ctypes.data, re.ctypes.data,
+                               rt.ctypes.data, rr.ctypes.data, e.ctypes.data, its.ctypes.data, conv.ctypes.data, rcs.ctypes.data)
+        out = []
+        for u, eng in enumerate(engines):
+            eng._check(int(rcs[u]))
+            k = int(nr[u])
+            out.append((list(zip(ri[u, :k].tolist(), re[u, :k].tolist(), rt[u, :k].tolist(), [bool(v) for v in rr[u, :k]])),
+                        float(e[u]), int(its[u]), bool(conv[u])))
+        return out
+
     def elbo(self):
         e = C.c_double()
         self._check(self.lib.vmr_elbo(self._h, C.byref(e)))

@@ -37,9 +37,15 @@ class SparseTensor:
 def layer_of(X, l):
     """Layer l of a [L,N,N,M] tensor as a one-layer tensor of the same kind (COO container or dense array)."""
     if is_sparse_like(X):
-        keep = np.asarray(X.subs[0]) == l
+        ls = np.asarray(X.subs[0])
+        shape = (1,) + tuple(int(v) for v in X.shape[1:])
+        if len(ls) == 0 or bool(np.all(ls[:-1] <= ls[1:])):   # layers in order (np.nonzero order, a sorted edge list): a slice, no copy
+            a, b = np.searchsorted(ls, [l, l + 1])
+            subs = (np.zeros(int(b - a), np.int64),) + tuple(np.asarray(c)[a:b] for c in X.subs[1:])
+            return SparseTensor(subs, np.asarray(X.vals)[a:b], shape=shape)
+        keep = ls == l
         subs = (np.zeros(int(keep.sum()), np.int64),) + tuple(np.asarray(a)[keep] for a in X.subs[1:])
-        return SparseTensor(subs, np.asarray(X.vals)[keep], shape=(1,) + tuple(int(v) for v in X.shape[1:]))
+        return SparseTensor(subs, np.asarray(X.vals)[keep], shape=shape)
     return np.ascontiguousarray(np.asarray(X)[l:l + 1])
 
 
