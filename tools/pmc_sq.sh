@@ -5,7 +5,7 @@ set -o pipefail
 OUT=${1:-gpurun_out/prof_sq}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 12 --warmup 1 --no-cpu-baseline --no-converge $BENCH_ARGS"
+B="python3 bench.py --steps 12 --warmup 1 --no-cpu-baseline --no-converge --no-extra --repeats 1 $BENCH_ARGS"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/p1 -- $B > $OUT/p1.log 2>&1 || echo "p1 failed"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/p2 -- $B > $OUT/p2.log 2>&1 || echo "p2 failed"
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/p3 -- $B > $OUT/p3.log 2>&1 || echo "p3 failed"

@@ -75,15 +75,16 @@ def main():
                 if "k_gamma_mask" in name: cls = "gamma_mask"
                 elif "k_gamma_counts" in name: cls = "gamma_counts"
                 elif "k_phi" in name: cls = "phi"
-                elif "k_rho" in name:
+                elif "k_rho" in name or "k_sweep_sl" in name:   # k_rho / k_rho_sp<K, MUT, UPDATE, ELBO..>, k_sweep_sl<K, UPDATE, ELBO, ALLFULL>
                     flags = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
-                    upd, elbo = flags[2] == "true", flags[3] == "true"
+                    o = 1 if "k_sweep_sl" in name else 2
+                    upd, elbo = flags[o] == "true", flags[o + 1] == "true"
                     cls = "rho_elbo" if (upd and elbo) else ("rho" if upd else ("elbo" if elbo else "gamma_counts"))
                 if cls:
                     traffic[cls] = rd + wb
         pj = os.path.join(dst, "pmc_traffic.json")
         cur = json.load(open(pj)) if os.path.exists(pj) else {}
-        cur["c3"] = traffic
+        cur[sys.argv[2] if len(sys.argv) > 2 else "c3"] = traffic
         json.dump(cur, open(pj, "w"), indent=1, sort_keys=True)
         print("traffic:", {k: f"{v/1e9:.3f} GB" for k, v in traffic.items()})
 

@@ -8,8 +8,8 @@ TAG=${1:-r01c}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1 || exit 2
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1 || exit 3
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/ea -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/ea.log 2>&1 || echo "ea counters unavailable"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --repeats 1 > $OUT/stats.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --repeats 1 > $OUT/fetch.log 2>&1 || exit 2
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --repeats 1 > $OUT/write.log 2>&1 || exit 3
+find $OUT -name '*agent_info.csv' -delete; find $OUT/stats -name '*kernel_trace.csv' -delete
 echo done

@@ -66,10 +66,13 @@ struct SlUnit { SlArgs a; Geo g; int blk0, nblk; };
 // (allfull: every mask row is all ones -- the variants without the mask code need a few registers fewer)
 constexpr bool sl_light(int K, bool elbo, bool allfull, bool update) { return !elbo && allfull && (K <= 2 || (!update && K <= 4)); }   // fits 128 registers
 constexpr int sl_tpb_max(int K, bool elbo, bool allfull, bool update = true) {
-  return elbo ? (K <= 4 ? 512 : 256) : (sl_light(K, elbo, allfull, update) ? 1024 : (K <= 4 ? 768 : 512));
+  return elbo ? (K <= 4 ? 512 : 256) : (sl_light(K, elbo, allfull, update) ? 1024 : (K <= 3 ? 768 : (K <= 7 ? 512 : 256)));
 }
+// ... and of the lockstep entry k_sweep_sl_b (its arguments come from memory: a few registers more than the same variant's own launch)
+constexpr int sl_tpb_max_b(int K, bool elbo, bool allfull) { return elbo ? sl_tpb_max(K, true, allfull) : (K <= 2 ? 768 : (K <= 7 ? 512 : 256)); }
+constexpr int sl_wpe_b(int K, bool elbo, bool allfull) { return elbo ? (K <= 4 ? 2 : 1) : (K <= 2 ? 3 : (K <= 7 ? 2 : 1)); }
 constexpr int sl_wpe(int K, bool elbo, bool allfull, bool update = true) {
-  return elbo ? (K <= 4 ? 2 : 1) : (sl_light(K, elbo, allfull, update) ? 4 : (K <= 4 ? 3 : 2));
+  return elbo ? (K <= 4 ? 2 : 1) : (sl_light(K, elbo, allfull, update) ? 4 : (K <= 3 ? 3 : (K <= 7 ? 2 : 1)));
 }
 
 // LDS bytes of one workgroup of the sweep kernel

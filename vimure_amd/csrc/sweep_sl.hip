@@ -750,7 +750,7 @@ __global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl(SlArgs a, Geo g) 
 // arguments from device memory.  A sweep of a Karnataka-sized layer is two dependent 20-40 us launches that leave the GPU
 // nearly empty; here every unit's sweep shares them.
 template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
-__global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl_b(const SlUnit* __restrict__ units, const int* __restrict__ blk_unit) {
+__global__ __launch_bounds__(sl_tpb_max_b(K, ELBO, ALLFULL), sl_wpe_b(K, ELBO, ALLFULL)) void k_sweep_sl_b(const SlUnit* __restrict__ units, const int* __restrict__ blk_unit) {
   const SlUnit& u = units[blk_unit[blockIdx.x]];
   sweep_body<K, UPDATE, ELBO, ALLFULL>(u.a, u.g, blockIdx.x - (unsigned)u.blk0, (unsigned)u.nblk);
 }

@@ -3848,7 +3848,7 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
   std::vector<FinUnit> fu(act.size());
   std::vector<int> gmap, rmap;
   for (int m = 0; m < 2; ++m) {
-    const int tpb = sl_tpb_max(K, m == 1, allfull, true), nw = tpb / 64;
+    const int tpb = sl_tpb_max_b(K, m == 1, allfull), nw = tpb / 64;
     // steps per wave: about one workgroup per CU in all (the tables in LDS allow few more, and a second round of workgroups
     // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each
     const long long per = std::max<long long>(4, std::min<long long>(64, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
