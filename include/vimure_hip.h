@@ -67,6 +67,10 @@ enum {
  *   mutuality: 0/1 (model.py:60-65; the host class forces 0 for undirected networks).
  *   eps: the EPS white-noise constant (model.py:215-218), normally 1e-12.
  * The handle is reusable across realisations and seeds (vmr_set_state restarts it).
+ * Environment, read here: VMR_DETERMINISTIC=1 makes the handle's sweeps bit-reproducible run to run (the reference's
+ * single-threaded NumPy, model.py:623-660, is): cross-workgroup sums as 64-bit integers in fixed point, one wave per workgroup
+ * with a fixed share of the work; report lists only (VMR_EINVAL otherwise), about a fifth of the default speed, vmr_sub_step
+ * returns VMR_ESTATE.
  */
 int vmr_create(vmr_handle* out, int device, int L, int N, int M, int K, int mutuality,
                const uint8_t* X, const uint8_t* R, int data_on_device, double eps);

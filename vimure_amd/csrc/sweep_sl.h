@@ -51,6 +51,11 @@ struct SlArgs {
   // the constant C (H_0 = C - D - sum_{k>0} H_k, D: the deficits of ties whose rho does not sum to 1), left there by
   // k_fin_gamma.  null: the pass does not touch nu.
   double* nu_acc; double* elbo_dev; int commit_nu;
+  // Deterministic mode (Geo::det): every sum that crosses workgroups is added as a 64-bit integer in fixed point (integer adds
+  // commute exactly) into these shadows -- [L][Y][Mp][K] H | [L][W*64][K] mask sums | [L][K] rho over all-ones rows | 4 ELBO
+  // partials | 1 nu share -- which k_det_fold turns into the doubles the finalize kernels read.  Inside a workgroup nothing
+  // needs it: a workgroup is ONE wave there and walks a fixed share of the steps in order.  null: floating-point atomics.
+  unsigned long long* det;
 #ifdef SL_DEBUG
   unsigned long long* dbg_t;   // [waves][4]: a wave's start, end of prologue, end of step loop, end (100 MHz clock)
 #endif

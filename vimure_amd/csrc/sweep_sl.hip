@@ -113,6 +113,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
+  // deterministic mode: the integer shadows (SlArgs::det)
+  unsigned long long* const dH = a.det ? a.det + (size_t)l * g.Y * Mp * K : nullptr;
+  unsigned long long* const dA = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)l * g.W * 64 * K : nullptr;
+  unsigned long long* const dF = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)l * K : nullptr;
+  unsigned long long* const dR = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)g.L * K : nullptr;   // [4], then the nu share
   const unsigned* rsl = a.rs + (size_t)l * (NS + 1);
   const unsigned* syl = a.sy + (size_t)l * NS;
   const unsigned* El = a.E + a.ebase[l];
@@ -141,7 +146,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   unsigned* tick = reinterpret_cast<unsigned*>(smem + off); off += 16;
   if (tid == 0) { tick[0] = 2u * (unsigned)nw; tick[1] = 0u; }   // ([1]: some step of this workgroup added a deficit)
   auto step_of = [&](unsigned t) SL_INL -> long long { return (long long)gb + (long long)t * Gl_; };
+  unsigned fixed_t = (unsigned)(2 * nw + wv);   // (deterministic mode: tickets wv, nw + wv, 2 nw + wv, ... -- a fixed share)
   auto draw = [&]() SL_INL -> long long {   // this wave's next ticket (one LDS atomic by lane 0)
+    if (a.det) { const unsigned t = fixed_t; fixed_t += (unsigned)nw; return step_of(t); }
     unsigned t = 0u;
     if (lane == 0) t = atomicAdd(tick, 1u);
     return step_of((unsigned)__builtin_amdgcn_readfirstlane((int)t));
@@ -551,10 +558,17 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             if (irr) atomicAdd(&Hc[row], dx * dfc);   // (wave-uniform: some tie of the step does not sum to 1)
             if (__any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
               if (fr && x != 0u) {   // table by the grid's last workgroup (nu_far).
-                double* d = Hl + (size_t)ym * K;
+                if (dH) {
+                  unsigned long long* d = dH + (size_t)ym * K;
 #pragma unroll
-                for (int k = 1; k < K; ++k) atomicAdd(&d[k], (double)x * r[k]);
-                if (dfc != 0.0) atomicAdd(&d[0], (double)x * dfc);
+                  for (int k = 1; k < K; ++k) atomicAdd(&d[k], det_fx((double)x * r[k], g.det_sh));
+                  if (dfc != 0.0) atomicAdd(&d[0], det_fx((double)x * dfc, g.det_sh));
+                } else {
+                  double* d = Hl + (size_t)ym * K;
+#pragma unroll
+                  for (int k = 1; k < K; ++k) atomicAdd(&d[k], (double)x * r[k]);
+                  if (dfc != 0.0) atomicAdd(&d[0], (double)x * dfc);
+                }
               }
               asm volatile("" ::: "memory");
             }
@@ -624,7 +638,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       }
     }
     a0p = block_sum_n(a0p, red);
-    if (tid == 0) atomicAdd(&a.nu_acc[0], a0p);
+    if (tid == 0) {
+      if (dR) atomicAdd(&dR[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
+    }
   }
   // the flush: every wave but the first when the first draws the ticket (it then has nothing else of its own outstanding)
   const int f0 = (nu_here && nw > 1) ? 64 : 0;
@@ -636,7 +652,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       const double v = Hc[q];
       if (v != 0.0) {
         const int k = q / (int)hcm, ym = q - k * (int)hcm;
-        atomicAdd(&Hl[(size_t)ym * K + k], v);
+        if (dH) atomicAdd(&dH[(size_t)ym * K + k], det_fx(v, g.det_sh)); else atomicAdd(&Hl[(size_t)ym * K + k], v);
       }
     }
   }
@@ -644,7 +660,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
     for (int q = tid - f0; q < g.M * K; q += nthr - f0) {
       const double v = As[q];
-      if (v != 0.0) atomicAdd(&out[q], v);
+      if (v != 0.0) { if (dA) atomicAdd(&dA[q], det_fx(v, DET_SH_A)); else atomicAdd(&out[q], v); }
     }
   }
   if (nu_here) {
@@ -678,6 +694,12 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
               for (int k = 1; k < K; ++k) vk[c][k - 1] = H0[(size_t)c * hcs + (size_t)it * K + k];
             }
+            if (a.det) {   // (deterministic mode: the far rows are in the integer shadow)
+              const unsigned long long* hi = a.det + (size_t)ll * hcs + (size_t)it * K;
+              v0[0] += det_back(hi[0], g.det_sh);
+#pragma unroll
+              for (int k = 1; k < K; ++k) vk[0][k - 1] += det_back(hi[k], g.det_sh);
+            }
             double h_[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) h_[k] = 0.0;
@@ -705,7 +727,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       }
       far = block_sum_n(far, red);
       if (tid == 0) {
-        double tot = atomicAdd(&a.nu_acc[0], 0.0) + far;   // device-scope read of every workgroup's share
+        double tot = far;   // + every workgroup's share (device-scope read)
+        if (dR) { tot += det_back(atomicAdd(&dR[4], 0ull), g.det_sh); dR[4] = 0ull; } else tot += atomicAdd(&a.nu_acc[0], 0.0);
         for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
         a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
         a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
@@ -723,7 +746,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       double v = block_sum_n(accF[k], red);
-      if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
+      if (tid == 0) { if (dF) atomicAdd(&dF[k], det_fx(v, DET_SH_A)); else atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v); }
     }
   }
   if (ELBO) {
@@ -732,7 +755,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     double v3 = block_sum_n(e_q, red);
     if (tid == 0) {
       double* out = a.slotR + (size_t)(bx % NSLOT) * 4;
-      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+      if (dR) { atomicAdd(&dR[1], det_fx(v1, g.det_shr)); atomicAdd(&dR[2], det_fx(v2, g.det_shr)); atomicAdd(&dR[3], det_fx(v3, g.det_shr)); }
+      else { atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3); }
     }
   }
 #ifdef SL_DEBUG

@@ -1981,7 +1981,7 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
 __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
                                                double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
                                                int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, const Geo& g,
-                                               const int bx) {
+                                               const int bx, const int det = 0 /*Geo::det: sums whose order would vary are integer or in slots*/) {
   extern __shared__ double dyn[];   // s1[mper]: sum_{y,k} w1 H per reporter; gthn[mper]: the new G_theta
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
@@ -2050,9 +2050,16 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
         if (y == 0) p0[k] += hv[k];
       }
     }
-    if (acc != 0.0) atomicAdd(&s1[m - m0], acc);
+    if (acc != 0.0) {
+      if (det) atomicAdd(reinterpret_cast<unsigned long long*>(&s1[m - m0]), det_fx(acc, g.det_sh));   // (threads of several waves add here)
+      else atomicAdd(&s1[m - m0], acc);
+    }
   }
   __syncthreads();
+  if (det) {
+    for (int m = tid; m < mper; m += FIN_TPB) s1[m] = det_back(*reinterpret_cast<unsigned long long*>(&s1[m]), g.det_sh);
+    __syncthreads();
+  }
   double pr[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) pr[k] = 0.0;
@@ -2113,7 +2120,10 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
   for (int k = 0; k < K; ++k) {
     const double v = block_sum_fin(pr[k], red);
     const double w = block_sum_fin(ps[k], red);
-    if (tid == 0) { atomicAdd(&finl[k], v); atomicAdd(&finl[KMAX + k], w); }
+    if (tid == 0) {
+      if (det) { double* sl_ = fin + (size_t)g.L * (2 * KMAX + 2) + ((size_t)l * FG_G + gq) * 2 * KMAX; sl_[k] = v; sl_[KMAX + k] = w; }   // its own slot
+      else { atomicAdd(&finl[k], v); atomicAdd(&finl[KMAX + k], w); }
+    }
   }
   // publish this workgroup's theta values (every storing wave drained, then one agent-scope release) before the ticket
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2131,7 +2141,12 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
   // ---- the layer's last workgroup: lambda, the factor table F, the LUT -------------------------------------------------
   if (tid < K) {
     const int k = tid, q = l * K + k;
-    const double sr = atomicAdd(&finl[k], 0.0), ss = atomicAdd(&finl[KMAX + k], 0.0);   // (device-scope reads)
+    double sr, ss;
+    if (det) {   // the workgroups' slots in order (published like the theta values: release before the ticket, acquire after it)
+      sr = 0.0; ss = 0.0;
+      const double* sl_ = fin + (size_t)g.L * (2 * KMAX + 2) + (size_t)l * FG_G * 2 * KMAX;
+      for (int q = 0; q < FG_G; ++q) { sr += __builtin_nontemporal_load(&sl_[q * 2 * KMAX + k]); ss += __builtin_nontemporal_load(&sl_[q * 2 * KMAX + KMAX + k]); }
+    } else { sr = atomicAdd(&finl[k], 0.0); ss = atomicAdd(&finl[KMAX + k], 0.0); }   // (device-scope reads)
     const double rte = par[o.b_la + q] + sr;
     if (g.mut && !do_phi) {
       par[o.p_rte_pend + q] = rte;   // the PHI sub-step commits (k_fin_phi)
@@ -2191,7 +2206,7 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
 }
 __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
                                                        double* lutg, double* Fg, double* fin, double* nu_acc, int nh, int do_phi, int consume, Geo g) {
-  fin_gamma_body(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x);
+  fin_gamma_body(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x, g.det);
 }
 // the finalize kernels of many small handles in one launch (vmr_fit_loop_batch): workgroup -> unit through blk_unit
 struct FinUnit {
@@ -2245,7 +2260,7 @@ __device__ __forceinline__ double gamma_elbo_term(double pa, double pb, double q
 #define FR_G 16   // workgroups per layer of k_fin_rho
 __device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
                                              double* fin, int do_nu, int do_elbo, int fold, int skip_nu /* the pass finished nu itself */, const Geo& g,
-                                             const int bx, const int gx) {
+                                             const int bx, const int gx, double* slots = nullptr /*deterministic mode: [gx][2] partial sums, summed in order*/) {
   __shared__ double red[8];
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
@@ -2285,8 +2300,8 @@ __device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const doub
   a0 = block_sum(a0, red);
   gt = block_sum(gt, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&fin[0], a0);
-    atomicAdd(&fin[1], gt);
+    if (slots) { slots[2 * bx] = a0; slots[2 * bx + 1] = gt; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+    else { atomicAdd(&fin[0], a0); atomicAdd(&fin[1], gt); }
     // the two adds are performed at the memory side before the ticket is drawn: they stay counted until they are (a full
     // __threadfence() -- L2 write-back and invalidate, ~3.5 us -- orders plain stores, of which the ticket publishes none)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2303,8 +2318,14 @@ __device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const doub
   }
   a1 = block_sum(a1, red); a2 = block_sum(a2, red); a3 = block_sum(a3, red);
   if (threadIdx.x == 0) {
-    a0 = atomicAdd(&fin[0], 0.0);   // device-scope reads of the other workgroups' sums
-    gt = atomicAdd(&fin[1], 0.0);
+    if (slots) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      a0 = 0.0; gt = 0.0;
+      for (int q = 0; q < gx; ++q) { a0 += __builtin_nontemporal_load(&slots[2 * q]); gt += __builtin_nontemporal_load(&slots[2 * q + 1]); }
+    } else {
+      a0 = atomicAdd(&fin[0], 0.0);   // device-scope reads of the other workgroups' sums
+      gt = atomicAdd(&fin[1], 0.0);
+    }
     fin[0] = 0.0; fin[1] = 0.0; fin[2] = 0.0;
     if (do_nu && g.mut) {
       sc[SC_G_NU_STALE] = sc[SC_G_NU];           // what the last cache refresh held (model.py:684)
@@ -2324,8 +2345,8 @@ __device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const doub
   }
 }
 __global__ __launch_bounds__(TPB) void k_fin_rho(double* par, double* Hg, const double* Cg, double* slotR, double* elbo_out,
-                                                 double* fin, int do_nu, int do_elbo, int fold, int skip_nu, Geo g) {
-  fin_rho_body(par, Hg, Cg, slotR, elbo_out, fin, do_nu, do_elbo, fold, skip_nu, g, (int)blockIdx.x, (int)gridDim.x);
+                                                 double* fin, int do_nu, int do_elbo, int fold, int skip_nu, Geo g, double* slots) {
+  fin_rho_body(par, Hg, Cg, slotR, elbo_out, fin, do_nu, do_elbo, fold, skip_nu, g, (int)blockIdx.x, (int)gridDim.x, slots);
 }
 // (lockstep launch: the ELBO of a sweep whose pass finished nu itself)
 __global__ __launch_bounds__(TPB) void k_fin_rho_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit) {
@@ -2461,7 +2482,8 @@ static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 // Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
-  SlShape s{std::max(64, std::min((update || elbo) ? h->sp_tpb : h->st_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0, update)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};   // (the variant's register budget caps its workgroup)
+  SlShape s{std::max(64, std::min((update || elbo) ? h->sp_tpb : h->st_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0, update)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};
+  if (g.det) s.tpb = 64;   // deterministic mode: a workgroup is one wave (its LDS adds then happen in program order)   // (the variant's register budget caps its workgroup)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -2512,7 +2534,7 @@ static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo, int skip_nu = 0) {
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->Cg, h->slotR, h->elbo_dev,
-                       h->elbo_dev + 4, do_nu, do_elbo, fold, skip_nu, g);
+                       h->elbo_dev + 4, do_nu, do_elbo, fold, skip_nu, g, g.det ? h->fr_slots : nullptr);
   }
   HIPCHK(h, hipGetLastError());
   if (fold) h->h_reduced = true;
@@ -2547,6 +2569,32 @@ static long long sp_grid_cap(const Geo& g, int tpb) {
 }
 
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
+// Deterministic mode: the integer shadows a pass left (SlArgs::det) become the doubles the finalize kernels read -- copy 0 of H,
+// slot 0 of the mask sums, of the all-ones sums and of the ELBO partials (the other copies / slots stay zero) -- and are zeroed.
+__global__ __launch_bounds__(256) void k_det_fold(unsigned long long* __restrict__ d, double* __restrict__ Hg, double* __restrict__ slotA,
+                                                 double* __restrict__ slotF, double* __restrict__ slotR, Geo g) {
+  const size_t nH = (size_t)g.Y * g.Mp * g.K, nA = (size_t)g.W * 64 * g.K, L = (size_t)g.L, K = (size_t)g.K;
+  const size_t tot = L * nH + L * nA + L * K + 4;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < tot; q += (size_t)gridDim.x * 256) {
+    const unsigned long long u = d[q];
+    if (u == 0ull) continue;
+    d[q] = 0ull;
+    if (q < L * nH) { const size_t l = q / nH, i = q - l * nH; Hg[l * NH * nH + i] += det_back(u, g.det_sh); }
+    else if (q < L * nH + L * nA) { const size_t r = q - L * nH, l = r / nA, i = r - l * nA; slotA[l * NSLOT * nA + i] += det_back(u, DET_SH_A); }
+    else if (q < L * nH + L * nA + L * K) { const size_t r = q - L * nH - L * nA, l = r / K, k = r - l * K; slotF[l * NSLOT * K + k] += det_back(u, DET_SH_A); }
+    else { const size_t r = q - L * nH - L * nA - L * K; slotR[r] += det_back(u, g.det_shr); }
+  }
+}
+static int det_fold(vmr_ctx* h) {
+  const Geo& g = h->g;
+  if (!g.det) return VMR_OK;
+  const size_t tot = (size_t)g.L * g.Y * g.Mp * g.K + (size_t)g.L * g.W * 64 * g.K + (size_t)g.L * g.K + 4;
+  hipLaunchKernelGGL(k_det_fold, dim3((unsigned)std::min<size_t>(1024, (tot + 255) / 256)), dim3(256), 0, h->stream, h->det_buf, h->Hg, h->slotA, h->slotF,
+                     h->slotR, g);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+
 // nu: -1 = the pass leaves nu alone; 0 = it leaves the raw sum in elbo_dev[1]; 1 = it also commits nu (sorted lists, see SlArgs::nu_acc)
 static int launch_hist(vmr_ctx* h, int nu = -1) {
   const Geo& g = h->g;
@@ -2560,9 +2608,11 @@ static int launch_hist(vmr_ctx* h, int nu = -1) {
       const SlShape shs = sl_shape(h, false, false, true);
       SlArgs as = sl_args(h, shs, 1, g.ml);
       if (nu >= 0 && g.mut) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = nu; }
+      as.det = g.det ? h->det_buf : nullptr;
       int rcs = sl_launch(h, 3, shs, as);
       if (rcs) return rcs;
       HIPCHK(h, hipGetLastError());
+      if ((rcs = det_fold(h))) return rcs;
       h->h_valid = true; h->h_zero = false; h->h_reduced = false;
       return VMR_OK;
     }
@@ -2707,7 +2757,9 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
       const SlShape shs = sl_shape(h, mode != 2, mode != 0, do_hist != 0);
       SlArgs as = sl_args(h, shs, do_hist, sum_a);
       if (nu_in_pass && do_hist) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = commit_nu ? 1 : 0; }
+      as.det = g.det ? h->det_buf : nullptr;
       if ((rc = sl_launch(h, mode, shs, as))) return rc;
+      if ((rc = det_fold(h))) return rc;
     } else {
     const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
     SpArgs s = sp_args(h, sh, do_hist, sum_a);
@@ -2823,7 +2875,8 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
   h->ncu = prop->multiProcessorCount;
   h->serial = getenv("VMR_SERIAL") != nullptr;
   h->use_graphs = getenv("VMR_GRAPH") != nullptr;   // off by default, see vmr_ctx::graphs
-  { const char* lf = getenv("VMR_LISTS"); h->sl = (lf && !strcmp(lf, "steps")) ? 0 : 1; }   // sorted report lists unless the older step layout is asked for
+  { const char* lf = getenv("VMR_LISTS"); h->sl = (lf && !strcmp(lf, "steps")) ? 0 : 1; }
+  { const char* dv = getenv("VMR_DETERMINISTIC"); g.det = (dv && atoi(dv) != 0) ? 1 : 0; g.det_sh = 0; g.det_shr = 0; }   // sorted report lists unless the older step layout is asked for
   const size_t rows = (size_t)L * N * N;
   CK(hipMalloc(&h->cov, rows));
   CK(hipMalloc(&h->rcls, rows));
@@ -3155,8 +3208,29 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
   CK(hipMalloc(&h->nu_acc, (size_t)(3 + L) * 8));   // the nu update inside the pass (SlArgs::nu_acc)
   CK(hipMemsetAsync(h->nu_acc, 0, (size_t)(3 + L) * 8, h->stream));
-  CK(hipMalloc(&h->fin_g, (size_t)L * (2 * KMAX + 2) * 8));   // k_fin_gamma: per layer 2 K sums and a ticket
-  CK(hipMemsetAsync(h->fin_g, 0, (size_t)L * (2 * KMAX + 2) * 8, h->stream));
+  // k_fin_gamma: per layer 2 K sums and a ticket; behind them, for the deterministic mode, every workgroup's own 2 K sums
+  CK(hipMalloc(&h->fin_g, ((size_t)L * (2 * KMAX + 2) + (size_t)L * FG_G * 2 * KMAX) * 8));
+  CK(hipMemsetAsync(h->fin_g, 0, ((size_t)L * (2 * KMAX + 2) + (size_t)L * FG_G * 2 * KMAX) * 8, h->stream));
+  if (g.det) {
+    // VMR_DETERMINISTIC=1 (sorted report lists only): see SlArgs::det.  The fixed point of the count-weighted sums leaves
+    // room for the sum of all counts.
+    if (!(h->sparse && h->sl)) return fail(nullptr, VMR_EINVAL, "VMR_DETERMINISTIC=1 needs the sorted report lists (a sparse tensor with M <= 8192, counts <= 2047)");
+    unsigned long long sx = 0;
+    CK(hipMemcpyAsync(&sx, h->sumx, 8, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    int bits = 1;
+    while (bits < 62 && (sx >> bits) != 0ull) ++bits;
+    g.det_sh = std::max(0, 61 - bits);
+    const unsigned long long eb = 64ull * (sx + (unsigned long long)L * g.N * g.N * K);
+    int rbits = 1;
+    while (rbits < 62 && (eb >> rbits) != 0ull) ++rbits;
+    g.det_shr = std::max(0, 61 - rbits);
+    const size_t nd = (size_t)L * g.Y * g.Mp * K + (size_t)L * g.W * 64 * K + (size_t)L * K + 5;
+    CK(hipMalloc(&h->det_buf, nd * 8));
+    CK(hipMemsetAsync(h->det_buf, 0, nd * 8, h->stream));
+    CK(hipMalloc(&h->fr_slots, (size_t)L * FR_G * 2 * 8));
+    CK(hipMemsetAsync(h->fr_slots, 0, (size_t)L * FR_G * 2 * 8, h->stream));
+  }
   CK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
   CK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
   if (h->sparse) {
@@ -3587,7 +3661,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3824,7 +3898,7 @@ static bool batch_steady(const vmr_ctx* h) {
 }
 static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
   // (a sweep of such a handle is k_fin_gamma + the pass, + k_fin_rho with an ELBO: the pass sums rho over the mask itself)
-  return h->sparse && h->sl && !h->g.two_pass && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
+  return h->sparse && h->sl && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
          h->g.K == h0->g.K && h->g.mut == h0->g.mut && (h->all_full != 0) == (h0->all_full != 0);
 }
 namespace {
@@ -4088,6 +4162,7 @@ int vmr_sub_step(vmr_handle h, int which) {
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sub_step");
   if (h->restored) return fail(h, VMR_ESTATE, "vmr_sub_step after vmr_restore: the restored state is read-only until the next vmr_set_state");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->g.det) return fail(h, VMR_ESTATE, "vmr_sub_step is not available with VMR_DETERMINISTIC=1 (whole sweeps only: vmr_step, vmr_fit_loop)");
   switch (which) {
     case VMR_STEP_GAMMA: return launch_gamma(h, false);
     case VMR_STEP_PHI: return launch_phi(h);

@@ -59,7 +59,14 @@ struct Geo {
   int dbg;      // timing experiments only (env VMR_DEBUG; results are wrong): dense path 1 = skip per-report math, 2 = skip
                 // the scan; report lists 8 = no H flush, 16 = no walk 1, 32 = no walk 2, 64 = no exp in the tie update
   double eps;
+  int det;      // VMR_DETERMINISTIC=1: bit-reproducible sweeps (one wave per workgroup, fixed step shares, integer cross-workgroup sums)
+  int det_sh;   // ... whose fixed point for count-weighted sums (H, the nu share) is 2^-det_sh: sum x of the dataset < 2^(62 - det_sh)
+  int det_shr;  // ... and 2^-det_shr for the ELBO partials (bounded by 64 (sum x + ties K))
 };
+// fixed point of the deterministic mode: count-weighted sums 2^-g.det_sh; ELBO partials 2^-g.det_shr; sums of rho over ties (< 2^31 ties) 2^-30
+#define DET_SH_A 30
+__device__ __forceinline__ unsigned long long det_fx(double v, int sh) { return (unsigned long long)__double2ll_rn(ldexp(v, sh)); }
+__device__ __forceinline__ double det_back(unsigned long long u, int sh) { return ldexp((double)(long long)u, -sh); }
 
 #define NSLOT 8   // accumulation slots per layer for cross-workgroup sums (global f64 atomics)
 
@@ -112,6 +119,8 @@ struct vmr_ctx {
   // (hipMalloc / hipFree during capture), so the eager path is the default.
   std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (sweeps in the graph, executable)
   bool use_graphs = false;
+  unsigned long long* det_buf = nullptr;   // deterministic mode: integer shadows of H (one copy), the mask sums, the ELBO partials, the nu share
+  double* fr_slots = nullptr;              // ... and k_fin_rho's per-workgroup partial sums [L * FR_G][2]
   double *rho_snap = nullptr, *par_snap = nullptr;   // vmr_snapshot: the best realisation so far (model.py:925-942)
   bool have_snap = false;
   bool restored = false;       // vmr_restore brought back rho and the parameters of another realisation, not its log prior: no sweeps until vmr_set_state
