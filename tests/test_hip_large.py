@@ -175,8 +175,8 @@ def test_dense_and_report_list_formats_agree(monkeypatch):
     (ed, ed2, sd), (es, es2, ss) = out["dense"], out["sparse"]
     np.testing.assert_allclose(es, ed, rtol=1e-11)
     assert abs(es2 - ed2) <= 1e-11 * abs(ed2)
-    for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):
-        np.testing.assert_allclose(ss[k], sd[k], rtol=1e-11)
+    for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):   # (four sweeps: differences of the last bits of rho have grown to 1e-11)
+        np.testing.assert_allclose(ss[k], sd[k], rtol=1e-10)
     np.testing.assert_allclose(ss["rho"], sd["rho"], rtol=1e-9, atol=1e-13)
 
 

@@ -949,49 +949,13 @@ __global__ __launch_bounds__(TPB, ELBO ? 2 : VMR_LB_RHO) void k_rho(RhoArgs a, G
 //
 // X is a tensor of COUNTS of which a few per cent are non-zero; every update touches only those, and the only
 // thing the mutuality terms need besides a report is the mirrored count X[l,j,i,m].  vmr_create therefore turns
-// the dense tensor into one 4-byte entry per non-zero count:
-//     bits 0..18  y * Mp + m  (mirror count y = X[l,j,i,m], 0 when mutuality is off; reporter m): the index of the
-//                 report's row in the per-(y, m) tables F and H
-//     bit 19      R[l,i,j,m]      bits 20..25  the tie's place in its step      bits 26..31  count x
-// (counts above 63 keep the dense tiles).  Ties are taken in STEPS of 64 consecutive ties -- what one wave of k_rho_sp
-// handles at a time, one tie per lane.  The entries of a step are stored in two parts (sliced-ELLPACK + a remainder):
-//   rounds   R_s full ROUNDS of 64 slots: slot `lane` of round r holds the r-th report of the step's tie `lane`, or 0
-//            when that tie has fewer.  A lane walks its own tie: sums stay in registers, no scatter.  R_s is the
-//            largest r for which at least half of the ties still have an r-th report (padding <= the slots it saves).
-//   rest     the reports beyond round R_s, round-major (every tie's next report, ties ascending), each naming its
-//            tie: walked entry-parallel, scattered into the ties' sums with LDS adds.  A trip of 64 consecutive
-//            entries holds (up to) 64 different consecutive ties -- consecutive LDS addresses, no collisions --
-//            until only the step's most reported tie is left (single-tie trips: wave reduction, one add).
-// rs[l][2s] / rs[l][2s+1] (u32) = first slot of step s / of its rest, relative to the layer's base; rcls[l][t] =
-// class of the tie's mask row (0 empty, 1 all ones, 2 partial; not read when every row is all ones), Qt[l][t] =
-// sum_m R[t,m] X[mirror(t),m] (the ELBO's mirror sum, a constant of the data).  A sweep reads 4 B per report (plus
-// the padding) + rho/log-prior instead of 1 B per (tie, reporter).  The dense tensor is freed once the lists exist.
+// the dense tensor into one 4-byte entry per non-zero count (layout and limits: sweep_sl.h), sorted by the ties'
+// report counts and laid out in steps of 64 ties (sorted_lists.hip); rcls[l][t] = class of the tie's mask row (0 empty,
+// 1 all ones, 2 partial; not read when every row is all ones), Qt[l][t] = sum_m R[t,m] X[mirror(t),m] (the ELBO's mirror
+// sum, a constant of the data).  A sweep reads 4 B per report + rho/log-prior instead of 1 B per (tie, reporter).  The
+// dense tensor is freed once the lists exist.  (Rounds 1-2 kept steps of 64 CONSECUTIVE ties with a scattered rest --
+// k_rho_sp, removed in round 3: DESIGN.md section 2.)
 // ==========================================================================================
-// SP_PF: slots per lane that are prefetched one step ahead (the first SP_PF*64 of a step).  Depth beats occupancy here: 8 trips
-// cover almost every step of the benchmark data (4.1 reports per tie), so the walks never wait for a load of their own;
-// measured at L=4 N=2000 M=200: 3 trips at 6 waves/SIMD 0.281 ms, 5 at 5: 0.257, 6 at 5: 0.251, 8 at 4: 0.239-0.248.
-#ifndef SP_PF
-#define SP_PF 8
-#endif
-#ifndef SP_PF_ELBO2
-#define SP_PF_ELBO2 6
-#endif
-#ifndef SP_LONG_KMAX
-#define SP_LONG_KMAX 4   // the LONG variants of k_rho_sp are compiled for K <= this (compile time)
-#endif
-#ifndef SP_QB
-#define SP_QB 3   // of those, the trips the common step takes in one batch (k_rho_sp's "quick" path); <= SP_PF.  (Batching all
-                  // full rounds among the prefetched trips, 4 or 5 at a time, was measured slower: fewer steps qualify.)
-#endif
-#define ENT_YM(e) ((e) & 0x7ffffu)
-#define ENT_INR(e) (((e) >> 19) & 1u)
-#define ENT_OW(e) ((int)(((e) >> 20) & 63u))
-#define ENT_X(e) ((e) >> 26)
-#define ENT_CMAX 63u   // largest count an entry holds
-#ifndef ELL_MIN_FILL
-#define ELL_MIN_FILL 32   // a round is stored in full while at least this many of the step's 64 ties reach it
-#endif
-
 __device__ __forceinline__ unsigned nz_bytes(uint4 v) {
   const unsigned M = 0x7f7f7f7fu;
   unsigned t0 = (((v.x & M) + M) | v.x) & ~M, t1 = (((v.y & M) + M) | v.y) & ~M;
@@ -1066,65 +1030,12 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned* a, const unsigned* _
 #pragma unroll
   for (int u = 0; u < 8; ++u) if (base + u < n) a[base + u] += add;
 }
-// Per step (one wave each): the number of full rounds R_s and the size of the rest; sz[2s] = 64 R_s, sz[2s+1] = rest
-// (exclusive scan of sz = the slot offsets rs).  rpl holds the per-tie counts (not yet scanned).
-__global__ __launch_bounds__(256) void k_sp_plan(const unsigned* __restrict__ rpl, unsigned* __restrict__ sz, Geo g) {
-  const int lane = threadIdx.x & 63;
-  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
-  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
-    const size_t t = s * 64 + lane;
-    const unsigned n = t < T ? rpl[t] : 0u;
-    // R = largest r with |{ties: n >= r}| >= ELL_MIN_FILL  (binary search; the count is non-increasing in r)
-    unsigned lo = 0, hi = (unsigned)g.M;
-    while (lo < hi) {
-      const unsigned mid = (lo + hi + 1) >> 1;
-      if (__popcll(__ballot(n >= mid)) >= ELL_MIN_FILL) lo = mid; else hi = mid - 1;
-    }
-    const unsigned R = lo;
-    unsigned rest = n > R ? n - R : 0u;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) rest += (unsigned)__shfl_xor((int)rest, o2, 64);
-    if (lane == 0) { sz[2 * s] = 64u * R; sz[2 * s + 1] = rest; }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) sz[2 * NS] = 0u;
-}
-
-// Place the entries of one layer: k_sp_fill wrote them tie-major (tie t's entries at rpl[t], reporters ascending; rpl
-// = exclusive scan of the per-tie counts); this kernel (one wave per step) moves them into the step's rounds and rest.
-__global__ __launch_bounds__(256) void k_sp_round(const unsigned* __restrict__ rpl, const unsigned* __restrict__ rsl,
-                                                  const unsigned* __restrict__ Ein, unsigned* __restrict__ Eout, Geo g) {
-  const int lane = threadIdx.x & 63;
-  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
-  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
-    const size_t t = s * 64 + lane;
-    const bool ok = t < T;
-    const unsigned r0 = rpl[ok ? t : T], n = rpl[ok ? t + 1 : T] - r0;
-    const unsigned ea = rsl[2 * s], et = rsl[2 * s + 1];
-    const unsigned R = (et - ea) >> 6;
-    // (Rotating each tie's reports by a per-tie offset, so that a round does not hold the r-th smallest reporter of all its 64
-    // ties -- neighbouring LDS addresses -- was tried: no gain, -2 % at config 3.)
-    for (unsigned r = 0; r < R; ++r) Eout[(size_t)ea + r * 64 + lane] = n > r ? Ein[(size_t)r0 + r] : 0u;
-    unsigned nmax = n;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, o2, 64));
-    unsigned base = 0;
-    for (unsigned r = R; r < nmax; ++r) {
-      const uint64_t bal = __ballot(n > r);
-      if (n > r) {
-        const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        Eout[(size_t)et + pos] = Ein[(size_t)r0 + r];
-      }
-      base += (unsigned)__popcll(bal);
-    }
-  }
-}
-
 // Write the entries of one layer (16 lanes per tie) and the mirror sums Qt.  rpl is the exclusive scan of the
 // per-tie counts: tie t's entries start at rpl[t], reporters ascending.
 template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
                                                  const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
-                                                 unsigned* __restrict__ Qtl, int sl, Geo g) {
+                                                 unsigned* __restrict__ Qtl, Geo g) {
   const int gl = threadIdx.x & 15;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
   for (size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4; t < Tr; t += (size_t)gridDim.x * 16) {
@@ -1135,7 +1046,6 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
     const uint8_t* mrow = Xl + tm * g.Mp;
     const uint64_t* rr = Rl + tc * g.W;
     const uint64_t* rmr = Rl + tm * g.W;
-    const unsigned own = (unsigned)(tc & 63) << 20;
     size_t pos = rpl[tc];
     unsigned q = 0;
     for (int c0 = 0; c0 < g.nchunk; c0 += 16) {   // uniform over the 16 lanes
@@ -1169,8 +1079,7 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
             y = (ys[u] >> sh) & 0xffu;
             if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
           }
-          El[w++] = sl ? ((y * (unsigned)g.Mp + (unsigned)m) | (inr << 20) | (x << 21))   // sorted lists (sweep_sl.h)
-                       : ((y * (unsigned)g.Mp + (unsigned)m) | (inr << 19) | own | (x << 26));
+          El[w++] = (y * (unsigned)g.Mp + (unsigned)m) | (inr << 20) | (x << 21);   // (sweep_sl.h)
         }
       }
       pos += tot;
@@ -1256,643 +1165,6 @@ __global__ __launch_bounds__(TPB) void k_mask_lists(const unsigned* __restrict__
   for (int q = threadIdx.x; q < g.M * K; q += TPB) {
     const double v = As[q];
     if (v != 0.0) atomicAdd(&out[q], v);
-  }
-}
-
-struct SpArgs {
-  const unsigned* E; const unsigned* rs; const unsigned long long* ebase; const uint64_t* Rb; const uint8_t* rcls;
-  double* rho; const double* logpr; const double* par; double* slotR; const double* lutg; double* Hg; double* slotF;
-  const unsigned* Qt;
-  const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask lists (null: read the mask words)
-  const double* Fg;   // per-report factors F[l][y][m][k], see k_build_f
-  int Gl, all_full;
-  int do_hist;        // 1: accumulate the statistics H; 2: "count mode" (vmr_create): rho = (0, 1, 0, ..) for every tie, slot 1 gets sum x
-  int yt, hc;         // levels (mirror counts 0..) of F / of the statistics H held in LDS
-  double* slotA;      // sum_a: the pass also sums the (new) rho over the listed reporters of the partial mask rows, A[l][m][k]
-  int sum_a;          // (what k_mask_lists does in a pass of its own), into this workgroup's slot of slotA
-};
-
-__global__ __launch_bounds__(256) void k_build_f(const double* __restrict__ par, double* __restrict__ Fg, Geo g) {
-  const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x, K = g.K;
-  const double gnu = par[o.sc + SC_G_NU];
-  double* Fl = Fg + (size_t)l * g.Y * g.Mp * K;
-  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < g.Y * g.Mp; it += gridDim.y * blockDim.x) {
-    const int y = it / g.Mp, m = it - y * g.Mp;
-    const double lth = par[o.l_th + (size_t)l * g.Mp + m], gth = par[o.G_th + (size_t)l * g.Mp + m];
-    for (int k = 0; k < K; ++k)
-      Fl[(size_t)it * K + k] = (m < g.M) ? f_entry(g.mut, lth, gth, par[o.l_la + l * K + k], par[o.G_la + l * K + k], gnu, y) : 0.0;
-  }
-}
-
-
-// rho update (UPDATE), ELBO data terms (ELBO) and the statistics H (a.do_hist) from the report lists.
-// A WAVE takes 64 consecutive ties per step, one per lane for the per-tie work (log prior, mask sum T, exp /
-// normalise, write-back); their entries are one contiguous run of the list and are walked entry-parallel
-// (coalesced 4-byte loads, lane <-> entry; an entry names its tie's lane).  Walk 1 gathers U_k = sum x F[y][m][k] per
-// tie with LDS atomics into the wave's own sums, walk 2 (after the per-tie update) adds x * rho_new into H and collects
-// the ELBO's log terms.  The waves of a workgroup (up to 16) share only the read-only tables and the LDS levels of H,
-// so the step loop has no workgroup barrier: waves drift apart and cover each other's latency; the next step's
-// per-tie values and first entries are prefetched into registers.
-#ifndef SP_TPB_MAX
-#define SP_TPB_MAX 1024
-#endif
-#ifndef SP_WPE
-#define SP_WPE 4   // waves per SIMD the kernel is compiled for (128 VGPRs: room for SP_PF = 8 prefetched trips, see there)
-#endif
-// Prefetch depth of a variant: as deep as its registers allow without spilling (128 VGPRs at 4 waves/SIMD; the ELBO
-// variants and many categories carry more state per tie)
-__host__ __device__ constexpr int sp_pf(int K, bool elbo) {
-  return elbo ? (K <= 2 ? SP_PF_ELBO2 : (K == 3 ? 6 : (K == 4 ? 4 : 3))) : (K <= 5 ? SP_PF : 4);
-}
-// LONG: the variant for datasets of long steps (many reports per tie, see the ring below); it carries 12 registers more and
-// costs 3 % on short-step data, so it is a variant of its own, chosen per dataset (vmr_ctx::long_steps), compiled for K <= 4.
-template <int K, bool MUT, bool UPDATE, bool ELBO, bool LONG = false>
-__global__ __launch_bounds__(SP_TPB_MAX, ELBO ? 4 : SP_WPE) void k_rho_sp(SpArgs a, Geo g) {   // (the ELBO variants carry more state: 128 VGPRs)
-  extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int PF = sp_pf(K, ELBO), QB = SP_QB < PF ? SP_QB : PF;   // prefetched trips per step; trips of the batched path
-  constexpr int RG = LONG ? 8 : 1;                                   // loads in flight in the further full rounds of a long step
-  const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
-  const int Mp = g.Mp;
-  const unsigned ytm = UPDATE ? (unsigned)a.yt * (unsigned)Mp : 0u;    // rows (y, m) of F held in LDS
-  const unsigned hcm = a.do_hist ? (unsigned)a.hc * (unsigned)Mp : 0u; // rows of H held in LDS
-  size_t off = 0;
-  double* F = reinterpret_cast<double*>(smem + off); off += (size_t)ytm * K * 8;             // [yt][Mp][K]
-  const int nHc = (int)hcm * (K - 1);
-  double* Hc = reinterpret_cast<double*>(smem + off); off += (size_t)nHc * 8;                 // [K-1][hc][Mp]: categories 1..K-1
-  double* Gth = reinterpret_cast<double*>(smem + off); off += ELBO ? (size_t)Mp * 8 : 0;
-  double* As = reinterpret_cast<double*>(smem + off); off += a.sum_a ? (size_t)Mp * K * 8 : 0;   // [Mp][K], see SpArgs::sum_a
-  double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
-  double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
-  double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;      // exp_tab / log_tab tables
-  double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
-  // wave-private, [K][64], for the rest of a step: the ties' sums U, then their new rho (ELBO variants: exp(rho) there and
-  // rho in rt)
-  double* ut = reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K; off += (size_t)nw * 64 * K * 8;
-  double* rt = ELBO ? reinterpret_cast<double*>(smem + off) + (size_t)wv * 64 * K : ut;
-  const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = blockIdx.x / a.Gl, gb = blockIdx.x - l * a.Gl;
-  const size_t T = (size_t)g.N * g.N;
-  const long long NS = (long long)((T + 63) / 64);   // steps of 64 ties; a workgroup owns a contiguous range, its waves interleave
-  const long long s0 = (long long)gb * NS / a.Gl, s1_ = (long long)(gb + 1) * NS / a.Gl;
-  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
-  const double* Fl = a.Fg + (size_t)l * g.Y * Mp * K;
-  for (int q = tid; q < (int)ytm * K; q += nthr) F[q] = Fl[q];
-  for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
-  if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
-  if (SP_TABLE_MATH && (UPDATE || ELBO)) sp_math_tables(xt, lt, tid, nthr);
-  if (ELBO) for (int m = tid; m < Mp; m += nthr) Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
-  const double* lut = a.lutg + (size_t)l * g.W * 256;
-  for (int w = tid; w < g.W; w += nthr) {
-    double v = 0.0;
-    for (int n = 0; n < 16; ++n) v += lut[(w * 16 + n) * 16 + 15];
-    wsum[w] = v;
-  }
-  double Ela[K], Gla[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; }
-  const double eps = g.eps;
-  const float rcp_mp = 1.0f / (float)Mp;
-  double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
-  double accF[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) accF[k] = 0.0;
-  double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
-  const unsigned* rsl = a.rs + (size_t)l * (2 * NS + 1);
-  const unsigned* El = a.E + a.ebase[l];
-  const uint64_t* Rl = a.Rb + (size_t)l * T * g.W;
-  const uint8_t* cl = a.rcls + (size_t)l * T;
-  const unsigned* Ql = a.Qt + (size_t)l * T;
-  double* rl = a.rho + (size_t)l * T * K;
-  const double* lpl = a.logpr + (size_t)l * T * K;
-  const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
-  const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
-  const double* Eth = a.par + o.E_th + (size_t)l * Mp;
-
-  // Software pipeline per wave: while step s is processed, the per-tie values and the first PF*64 slots of
-  // the wave's next step and the slot range of the one after are in flight.
-  unsigned clsn = 0, qn = 0;
-  double lpn[K], rn[K];
-  unsigned pen[PF];
-  unsigned ea1 = 0, et1 = 0, ee1 = 0;
-  unsigned rg2 = 0;   // lanes 0..2: the slot range of the step after next.  Kept in a VECTOR register until it is needed, one step
-                      // later: read as scalars (uniform address), the three values were waited for on the spot, in every step.
-  auto fetch_range = [&](long long s, unsigned& ea, unsigned& et, unsigned& ee) { ea = rsl[2 * s]; et = rsl[2 * s + 1]; ee = rsl[2 * s + 2]; };
-  auto fetch_range_v = [&](long long s) { rg2 = lane < 3 ? rsl[2 * s + lane] : 0u; };
-  auto fetch_tie = [&](long long s, unsigned ea, unsigned ee) {
-    const size_t t = (size_t)s * 64 + lane;
-    const bool ok = t < T;
-    clsn = ok ? (a.all_full ? 1u : (unsigned)cl[t]) : 0u;
-    if (ELBO && MUT) qn = ok ? Ql[t] : 0u;
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lpn[k] = 0.0; rn[k] = 0.0; }
-    if ((UPDATE || ELBO) && ok) load_k<K>(lpl + t * K, lpn);
-    if (!UPDATE && ok && a.do_hist != 2) load_k<K>(rl + t * K, rn);
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-      const unsigned q = (unsigned)lane + (unsigned)j * 64;
-      unsigned v = 0u;
-      if (q < ee - ea) v = El[(size_t)ea + q];
-      pen[j] = v;
-    }
-  };
-  const long long sfirst = s0 + wv;
-  if (sfirst < s1_) {
-    fetch_range(sfirst, ea1, et1, ee1);
-    if (sfirst + nw < s1_) fetch_range_v(sfirst + nw);
-    fetch_tie(sfirst, ea1, ee1);
-  }
-  __syncthreads();   // tables
-  double Tfull = 0.0;
-  for (int w = 0; w < g.W; ++w) Tfull += wsum[w];
-
-  // the K factors of a report's (y, m) row: LDS copy of the populous levels, the global table beyond
-  // (NEAR: every level is in LDS -- decided once per launch, so the walks carry no per-trip test for the other case)
-  const bool all_near = (!UPDATE || a.yt >= g.Y) && (!a.do_hist || a.hc >= g.Y);
-  auto f_row = [&](unsigned ym, double (&f)[K], auto near) {
-    if (decltype(near)::value) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) f[k] = F[ym * K + k];
-      return;
-    }
-    const bool far = ym >= ytm;
-    const unsigned il = (far ? 0u : ym) * K;
-#pragma unroll
-    for (int k = 0; k < K; ++k) f[k] = F[il + k];
-    if (__any(far)) {
-      if (far) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) f[k] = Fl[(size_t)ym * K + k];
-        // wait for it HERE: f[] would otherwise carry a pending global load past the join, and the compiler, unable to
-        // count it there, would drain every outstanding load (the next step's prefetch) with vmcnt(0) in ALL trips
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-        asm volatile("" ::: "memory");   // keeps the two address spaces apart (no select of pointers -> flat loads)
-      }
-    }
-  };
-  // one report into H: categories 1..K-1 only -- sum_k rho_k = 1, so H_0 = (sum of x, a constant of the data) - sum_{k>0} H_k
-  // is rebuilt when the copies of H are folded (h_fold_item).  Slot 0 (global only) collects x * (1 - sum_k rho_k) of the ties
-  // whose rho does not sum to 1 (an all-zero row after underflow, model.py:808-811; rows of a user-supplied prior): dfc.
-  auto h_add = [&](unsigned ym, const double (&xr)[K], double xd, bool on, auto near) {
-    if (on) {
-      if (decltype(near)::value || ym < hcm) {
-#pragma unroll
-        for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], xr[k]);
-      } else {   // a level beyond the LDS copy (rare)
-        double* d = Hl + (size_t)ym * K;
-#pragma unroll
-        for (int k = 1; k < K; ++k) atomicAdd(&d[k], xr[k]);
-        asm volatile("" ::: "memory");   // (as above: no flat atomics)
-      }
-      if (xd != 0.0) atomicAdd(&Hl[(size_t)ym * K], xd);
-    }
-  };
-  auto elbo_log = [&](unsigned ent, unsigned ym, double dx, const double (&er)[K]) {   // x log(sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps)
-    unsigned y = (unsigned)((float)ym * rcp_mp);
-    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
-    const unsigned m = ym - y * (unsigned)Mp;
-    double inner = 0.0;
-    if (ENT_INR(ent)) {
-      const double z2 = gnu * (double)y, gt = Gth[m];
-#pragma unroll
-      for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
-    }
-    e_log += dx * (SP_TABLE_MATH ? log_tab(inner + eps, lt) : log_pos(inner + eps));
-  };
-
-  // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749).  Lanes of a
-  // wave are consecutive ties (i, j..j+63): with a self-reporter mask one of the two listed reporters is the same for (almost)
-  // all of them -- reduced across the wave before ONE add -- and the other one differs from lane to lane.
-  auto add_lists = [&](size_t t, bool on, const double (&rr)[K]) {
-    unsigned q0 = 0, q1 = 0;
-    if (on) { q0 = rql[t]; q1 = rql[t + 1]; }
-    for (unsigned i = 0;; ++i) {
-      const bool v = q0 + i < q1;
-      const unsigned long long vm = __ballot(v);
-      if (vm == 0ull) break;
-      const int m = v ? (int)Rml[q0 + i] : -1;
-      const int m0 = __builtin_amdgcn_readlane(m, __builtin_ctzll(vm));
-      if (__all(!v || m == m0)) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const double sm_ = wave_sum(v ? rr[k] : 0.0);
-          if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
-        }
-      } else if (v) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
-      }
-    }
-  };
-
-  for (long long s = sfirst; s < s1_; s += nw) {
-    const size_t t = (size_t)s * 64 + lane;
-    const bool act = t < T;
-    const unsigned cls = clsn, qt = qn;
-    const unsigned ea = ea1, nt = ee1 - ea1;          // the step's slots: full rounds, then the rest
-    const int R = (int)((et1 - ea1) >> 6);            // full rounds (trips in which lane <-> tie)
-    const int trips = (int)((nt + 63) >> 6);
-    const bool has_rest = ee1 > et1;
-    double lp[K], r[K];
-    unsigned pe[PF];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lp[k] = lpn[k]; r[k] = rn[k]; }
-#pragma unroll
-    for (int j = 0; j < PF; ++j) pe[j] = pen[j];
-    // Long steps (more full rounds than prefetched trips; a config-5 layer has 19 reports per tie): their further full rounds
-    // keep RG loads in flight -- issued RG trips ahead of their use, the first RG here at the top of the step; prefetching one
-    // trip ahead left every trip waiting for memory -- and take a body without the rest's bookkeeping.
-    unsigned rg[RG];
-    auto ring_fill = [&]() {
-#pragma unroll
-      for (int i = 0; i < RG; ++i) rg[i] = (PF + i < R) ? El[(size_t)ea + (unsigned)lane + (unsigned)(PF + i) * 64] : 0u;
-    };
-    auto ring_walk = [&](auto&& body) {
-      for (int j0 = PF; j0 < R; j0 += RG) {
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-          if (j0 + i < R) {   // (wave-uniform)
-            const unsigned cur = rg[i];
-            const int jn = j0 + i + RG;
-            rg[i] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
-            body(cur);
-          }
-        }
-      }
-    };
-    const int jr = (LONG && R > PF) ? R : PF;   // first trip of the one-ahead loops below: the rest of a long step
-    if (LONG && R > PF) ring_fill();
-    if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
-#pragma unroll
-      for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
-    }
-    bool quick_w2 = false;   // walk 1 found the prefetched trips to be full rounds of LDS levels (see there)
-    double dfc = 0.0;   // 1 - sum_k rho_k of this lane's tie, 0 when that is rounding
-    bool irr = false;   // (wave-uniform) some tie of the step has a non-zero dfc
-    double er[K];       // exp(rho) of this lane's tie (ELBO, model.py:971)
-    auto put_rho = [&](bool exact_one) {   // the tie's rho for walk 2
-      if (!exact_one) {
-        double sm = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) sm += r[k];
-        dfc = 1.0 - sm;
-        if (fabs(dfc) <= 1e-14 || !act) dfc = 0.0;   // rounding of the normalisation
-        irr = a.do_hist && __any(dfc != 0.0);
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (ELBO) er[k] = SP_TABLE_MATH ? exp_tab(r[k], xt) : exp(r[k]);   // (rho in [0, 1])
-        if (has_rest) {   // the rest's reports look their tie up in LDS: slot 0 = dfc, categories 1.. as they are
-          rt[k * 64 + lane] = (k == 0) ? dfc : r[k];
-          if (ELBO) ut[k * 64 + lane] = er[k];
-        }
-      }
-    };
-    if (UPDATE) {
-      if (has_rest) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) ut[k * 64 + lane] = 0.0;
-      }
-    } else {
-      put_rho(false);
-      if (!ELBO && a.do_hist == 1 && act && cls == 1u) {   // statistics of the CURRENT rho: all-ones mask rows are summed here too
-#pragma unroll
-        for (int k = 0; k < K; ++k) accF[k] += r[k];
-      }
-      if (!ELBO && a.sum_a) add_lists(t, act && cls == 2u, r);
-    }
-    // next steps' loads
-    if (s + nw < s1_) {
-      ea1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 0);
-      et1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 1);
-      ee1 = (unsigned)__builtin_amdgcn_readlane((int)rg2, 2);
-      if (s + 2 * nw < s1_) fetch_range_v(s + 2 * nw);
-      fetch_tie(s + nw, ea1, ee1);
-    }
-    double Tt = 0.0;
-    bool rowfull = false;
-    if (UPDATE || ELBO) {   // T = sum_m R E[theta_m] (model.py:766-792)
-      if (cls == 1u) { Tt = Tfull; rowfull = true; }
-      else if (cls == 2u && a.rq) {   // a short list of reporters
-        const unsigned q0 = rql[t], q1 = rql[t + 1];
-        for (unsigned q = q0; q < q1; ++q) Tt += Eth[Rml[q]];
-      } else if (cls == 2u) {
-        const uint64_t* rwt = Rl + t * g.W;
-        for (int w = 0; w < g.W; ++w) {
-          uint64_t bits = rwt[w];
-          if (bits == ~0ull) { Tt += wsum[w]; continue; }
-          for (int n = 0; bits != 0; ++n, bits >>= 4) Tt += lut[((w * 16 + n) << 4) + (unsigned)(bits & 15u)];
-        }
-      }
-    }
-    wave_sync();   // everything below is wave-local: LDS operations of a wave complete in order
-
-    if (UPDATE) {
-      // walk 1: U_k of every tie = sum x F[y][m][k].  Full rounds: this lane's own tie, in registers; the rest: LDS adds.
-      double U[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) U[k] = 0.0;
-      auto trip1 = [&](unsigned ent, int j, auto near) {
-        double f[K];
-        f_row(ENT_YM(ent), f, near);
-        const double dx = (double)ENT_X(ent);   // (an empty slot has x = 0)
-        if (j < R) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
-        } else {
-          const bool v = (unsigned)lane + (unsigned)j * 64 < nt;
-          const int ow = ENT_OW(ent);
-          const int o0 = __builtin_amdgcn_readfirstlane(ow);   // (lane 0 of a trip always holds a report)
-          if (__all(ow == o0 || !v)) {   // all of them inside one tie (a tie most reporters report on): reduce, then one add
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const double sm_ = wave_sum(dx * f[k]);
-              if (lane == 0) atomicAdd(&ut[k * 64 + o0], sm_);
-            }
-          } else if (v) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) atomicAdd(&ut[k * 64 + ow], dx * f[k]);
-          }
-        }
-      };
-      const int trips1 = (g.dbg & 16) ? 0 : trips;   // (timing experiment: no walk 1)
-      // The common step: its first QB trips are all full rounds and none of their reports is in a level beyond the LDS
-      // tables.  Then the QB table reads are issued back to back and consumed afterwards -- one LDS latency instead of
-      // QB, and no branch per trip (an empty slot has x = 0 and reads row 0).
-      bool quick = R >= QB && trips1 > 0;
-      if (quick) {
-        bool far = false;
-#pragma unroll
-        for (int j = 0; j < QB; ++j) far = far || ENT_YM(pe[j]) >= ytm || (a.do_hist && ENT_YM(pe[j]) >= hcm);
-        quick = !__any(far);
-      }
-      quick_w2 = quick;
-      auto walk1 = [&](auto near) {
-        if (quick) {
-          double f[QB][K];
-#pragma unroll
-          for (int j = 0; j < QB; ++j) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) f[j][k] = F[ENT_YM(pe[j]) * K + k];
-          }
-#pragma unroll
-          for (int j = 0; j < QB; ++j) {
-            const double dx = (double)ENT_X(pe[j]);
-#pragma unroll
-            for (int k = 0; k < K; ++k) U[k] = fma(dx, f[j][k], U[k]);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-          if ((j >= QB || !quick) && j < trips1) trip1(pe[j], j, near);   // wave-uniform
-        }
-        if (LONG && R > PF && trips1 > 0) {
-          auto single = [&](unsigned ent) {
-            double f[K];
-            f_row(ENT_YM(ent), f, near);
-            const double dx = (double)ENT_X(ent);
-#pragma unroll
-            for (int k = 0; k < K; ++k) U[k] = fma(dx, f[k], U[k]);
-          };
-          // groups of GB trips whose rows are all in the LDS levels: their table reads are issued back to back (one LDS latency
-          // per group, as in the batched path of the prefetched trips)
-          constexpr int GB = K <= 2 ? 4 : 2;
-          for (int j0 = PF; j0 < R; j0 += RG) {
-#pragma unroll
-            for (int gi = 0; gi < RG; gi += GB) {
-              if (j0 + gi + GB - 1 < R) {   // (wave-uniform)
-                unsigned c[GB];
-                bool far = false;
-#pragma unroll
-                for (int u = 0; u < GB; ++u) {
-                  c[u] = rg[gi + u];
-                  const int jn = j0 + gi + u + RG;
-                  rg[gi + u] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
-                  far = far || ENT_YM(c[u]) >= ytm;
-                }
-                if (decltype(near)::value || !__any(far)) {
-                  double f[GB][K];
-#pragma unroll
-                  for (int u = 0; u < GB; ++u) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) f[u][k] = F[ENT_YM(c[u]) * K + k];
-                  }
-#pragma unroll
-                  for (int u = 0; u < GB; ++u) {
-                    const double dx = (double)ENT_X(c[u]);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) U[k] = fma(dx, f[u][k], U[k]);
-                  }
-                } else {
-#pragma unroll
-                  for (int u = 0; u < GB; ++u) single(c[u]);
-                }
-              } else {
-#pragma unroll
-                for (int u = 0; u < GB; ++u) {
-                  if (j0 + gi + u < R) {
-                    const unsigned cur = rg[gi + u];
-                    const int jn = j0 + gi + u + RG;
-                    rg[gi + u] = jn < R ? El[(size_t)ea + (unsigned)lane + (unsigned)jn * 64] : 0u;
-                    single(cur);
-                  }
-                }
-              }
-            }
-          }
-          if (a.do_hist || ELBO) ring_fill();   // (walk 2 goes over the same trips: from the L2 now)
-        }
-        if (trips1 > jr) {   // the rest of a long step: one trip ahead
-          unsigned q = (unsigned)lane + (unsigned)jr * 64;
-          unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = jr; j < trips; ++j) {
-            const unsigned cur = nx;
-            q += 64;
-            nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
-            trip1(cur, j, near);
-          }
-        }
-      };
-      if (all_near) walk1(std::true_type{}); else walk1(std::false_type{});
-      if (has_rest) {
-        wave_sync();
-#pragma unroll
-        for (int k = 0; k < K; ++k) U[k] += ut[k * 64 + lane];
-      }
-      // per-tie update from the finished sums
-      double aa[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) aa[k] = (lp[k] + U[k]) - Tt * Ela[k];
-      bool done = false;
-      if (K == 2) {
-        // two categories: rho_0 = 1 / (1 + e^(a1-a0)) -- one exp, one divide -- wherever the reference's raw
-        // exponentials neither overflow nor underflow (then equal to exp(a_k) / sum up to rounding); other ties below
-        const double d = aa[1] - aa[0];
-        const bool safe = fabs(aa[0]) < 700.0 && fabs(aa[1]) < 700.0 && fabs(d) < 700.0;
-        if (__all(safe)) {
-          const double e = (g.dbg & 64) ? d : (SP_TABLE_MATH ? exp_tab(d, xt) : exp(d));   // (dbg 64: timing experiment, no exp)
-          r[0] = 1.0 / (1.0 + e);
-          r[1] = e * r[0];
-          done = true;
-        }
-      }
-      if (!done) {
-        double sum = 0.0;
-        bool tame = SP_TABLE_MATH != 0;   // every a_k of the wave's ties where exp neither overflows nor underflows (else: the library's)
-#pragma unroll
-        for (int k = 0; k < K; ++k) tame = tame && fabs(aa[k]) < 700.0;
-        tame = __all(tame);
-        if (tame) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) r[k] = exp_tab(aa[k], xt);
-        } else {
-#pragma unroll
-          for (int k = 0; k < K; ++k) r[k] = exp(aa[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) sum += r[k];   // no max-subtraction, as model.py:807
-        if (sum > 0.0) {   // model.py:808-811; a true divide: 1/sum overflows when sum is subnormal
-#pragma unroll
-          for (int k = 0; k < K; ++k) r[k] /= sum;
-        }
-      }
-      if (act) {
-        store_k<K>(rl + t * K, r);
-#pragma unroll
-        for (int k = 0; k < K; ++k) accF[k] += rowfull ? r[k] : 0.0;
-      }
-      if (a.sum_a) add_lists(t, act && cls == 2u, r);
-      if (has_rest) wave_sync();   // (U of the rest is consumed; without the ELBO rt aliases ut)
-      put_rho(done);
-      if (has_rest) wave_sync();
-    }
-    if ((a.do_hist || ELBO) && !(g.dbg & 32)) {   // walk 2: H of the (new) rho; ELBO log terms   (dbg 32: timing experiment without it)
-      auto trip2 = [&](unsigned ent, int j, auto near) {
-        const unsigned ym = ENT_YM(ent);
-        const double dx = (double)ENT_X(ent);
-        double xr[K];
-        if (j < R) {   // this lane's own tie
-#pragma unroll
-          for (int k = 1; k < K; ++k) xr[k] = dx * r[k];
-          if (a.do_hist) h_add(ym, xr, irr ? dx * dfc : 0.0, ENT_X(ent) != 0u, near);
-          if (ELBO) elbo_log(ent, ym, dx, er);
-        } else if ((unsigned)lane + (unsigned)j * 64 < nt) {
-          const int ow = ENT_OW(ent);
-#pragma unroll
-          for (int k = 1; k < K; ++k) xr[k] = dx * rt[k * 64 + ow];
-          if (a.do_hist) h_add(ym, xr, irr ? dx * rt[ow] : 0.0, true, near);
-          if (ELBO) {
-            double eo[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) eo[k] = ut[k * 64 + ow];
-            elbo_log(ent, ym, dx, eo);
-          }
-        }
-      };
-      const bool quick2 = UPDATE && a.do_hist && R >= QB && !irr && !(g.dbg & 16) && quick_w2;
-      auto walk2 = [&](auto near) {
-        if (quick2) {   // (as in walk 1: the first QB trips are full rounds of LDS levels; this lane's own rho)
-          double in_[QB];
-#pragma unroll
-          for (int j = 0; j < QB; ++j) {
-            const unsigned ym = ENT_YM(pe[j]), x = ENT_X(pe[j]);
-            const double dx = (double)x;
-            if (x != 0u) {
-#pragma unroll
-              for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)(k - 1) * hcm + ym], dx * r[k]);
-            }
-            if (ELBO) {   // the QB logarithms are independent: straight-line, so that they interleave
-              unsigned y = (unsigned)((float)ym * rcp_mp);
-              if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
-              const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
-              double inner = 0.0;
-#pragma unroll
-              for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
-              in_[j] = (ENT_INR(pe[j]) ? inner : 0.0) + eps;
-            }
-          }
-          if (ELBO) {
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-              const unsigned x = ENT_X(pe[j]);
-              const double lg = SP_TABLE_MATH ? log_tab(in_[j], lt) : log_pos(in_[j]);
-              e_log += x != 0u ? (double)x * lg : 0.0;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-          if ((j >= QB || !quick2) && j < trips) trip2(pe[j], j, near);
-        }
-        if (LONG && R > PF) {
-          ring_walk([&](unsigned ent) {   // this lane's own tie
-            const unsigned ym = ENT_YM(ent);
-            const double dx = (double)ENT_X(ent);
-            double xr[K];
-#pragma unroll
-            for (int k = 1; k < K; ++k) xr[k] = dx * r[k];
-            if (a.do_hist) h_add(ym, xr, irr ? dx * dfc : 0.0, ENT_X(ent) != 0u, near);
-            if (ELBO) elbo_log(ent, ym, dx, er);
-          });
-        }
-        if (trips > jr) {
-          unsigned q = (unsigned)lane + (unsigned)jr * 64;
-          unsigned nx = q < nt ? El[(size_t)ea + q] : 0u;
-          for (int j = jr; j < trips; ++j) {
-            const unsigned cur = nx;
-            q += 64;
-            nx = (j + 1 < trips && q < nt) ? El[(size_t)ea + q] : 0u;
-            trip2(cur, j, near);
-          }
-        }
-      };
-      if (all_near) walk2(std::true_type{}); else walk2(std::false_type{});
-    }
-    if (ELBO && act) {
-      double sr = 0.0, se = 0.0, en = 0.0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        sr += r[k]; se += r[k] * Ela[k];
-        en += r[k] * lp[k] - r[k] * (SP_TABLE_MATH ? log_tab(r[k] + eps, lt) : log_pos(r[k] + eps));   // model.py:1306-1313
-      }
-      e_lin += en - se * Tt;
-      if (MUT) e_q += sr * (double)qt;
-    }
-    if (has_rest) wave_sync();
-  }
-  __syncthreads();
-  if (a.do_hist && !(g.dbg & 8)) {   // flush the LDS levels ([K-1][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
-    for (int q = tid; q < nHc; q += nthr) {
-      const double v = Hc[q];
-      if (v != 0.0) {
-        const int k1 = q / (int)hcm, ym = q - k1 * (int)hcm;
-        atomicAdd(&Hl[(size_t)ym * K + k1 + 1], v);
-      }
-    }
-  }
-  if (a.sum_a) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K], as k_mask_lists)
-    double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
-    for (int q = tid; q < g.M * K; q += nthr) {
-      const double v = As[q];
-      if (v != 0.0) atomicAdd(&out[q], v);
-    }
-  }
-  if (UPDATE || (!ELBO && a.do_hist == 1)) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      double v = block_sum_n(accF[k], red);
-      if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
-    }
-  }
-  if (ELBO) {
-    double v1 = block_sum_n(e_lin, red);
-    double v2 = block_sum_n(e_log, red);
-    double v3 = block_sum_n(e_q, red);
-    if (tid == 0) {
-      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
-      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
-    }
   }
 }
 
@@ -2456,34 +1728,13 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
   return n + 16;
 }
 
-// LDS bytes of one k_rho_sp workgroup of tpb threads: F levels, H levels, G_theta (ELBO), per-wave tie sums
-static size_t shmem_sp(const Geo& g, int tpb, int yt, int hc, bool update, bool elbo, bool hist) {
-  const size_t lb = (size_t)g.Mp * g.K * 8;
-  return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * (lb / g.K) * (g.K - 1) : 0) + (elbo ? (size_t)g.Mp * 8 : 0) + (size_t)g.W * 8 + 128 +
-         (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 +
-         (size_t)(tpb / 64) * 64 * g.K * 8 * (elbo ? 2 : 1) + 16;
-}
 #define SP_LDS_MAX (160 * 1024)
-// Launch shape of one k_rho_sp variant: the handle's block size and table levels, shrunk until the workgroup fits
-// in LDS (the ELBO variants carry more per-wave state; levels that do not fit are read from / added to global memory).
-struct SpShape { int tpb, yt, hc; size_t smem; };
-static SpShape sp_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
-  const Geo& g = h->g;
-  SpShape s{h->sp_tpb, update ? g.yt : 0, hist ? g.hc : 0, 0};
-  auto bytes = [&]() { return shmem_sp(g, s.tpb, s.yt, s.hc, update, elbo, hist); };
-  while (bytes() > SP_LDS_MAX && s.tpb > 256) s.tpb >>= 1;
-  while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
-  while (bytes() > SP_LDS_MAX && s.tpb > 64) s.tpb >>= 1;
-  s.smem = bytes();
-  return s;
-}
-
 
 // Launch shape of one sweep over the sorted lists: the handle's block size and table levels, shrunk until the workgroup fits in LDS
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
   SlShape s{std::max(64, std::min((update || elbo) ? h->sp_tpb : h->st_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0, update)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};
-  if (g.det) s.tpb = 64;   // deterministic mode: a workgroup is one wave (its LDS adds then happen in program order)   // (the variant's register budget caps its workgroup)
+  if (g.det) s.tpb = 64;   // deterministic mode: a workgroup is one wave (its LDS adds then happen in program order)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -2551,10 +1802,6 @@ static int ensure_h_folded(vmr_ctx* h) {
   return VMR_OK;
 }
 
-static SpArgs sp_args(const vmr_ctx* h, const SpShape& sh, int do_hist, int sum_a = 0) {
-  return SpArgs{h->E, h->rs, h->ebase, h->Rb, h->rcls, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, h->Qt,
-                h->rq, h->Rm, h->rbase, h->Fg, 1, h->all_full, do_hist, sh.yt, sh.hc, h->slotA, sum_a};
-}
 // The pass about to be launched adds the mask-list sums of its rho into slotA: whatever an earlier pass left there unconsumed goes
 static int begin_sum_a(vmr_ctx* h, hipStream_t st) {
   const Geo& g = h->g;
@@ -2562,12 +1809,6 @@ static int begin_sum_a(vmr_ctx* h, hipStream_t st) {
   h->a_zero = false;
   return VMR_OK;
 }
-// steps of 64 ties per layer / waves per workgroup: at least one step per wave
-static long long sp_grid_cap(const Geo& g, int tpb) {
-  const long long NS = ((long long)g.N * g.N + 63) / 64, nw = tpb / 64;
-  return (NS + nw - 1) / nw;
-}
-
 // H of the current rho (start of a fit / after vmr_set_state; the rho pass keeps it current afterwards)
 // Deterministic mode: the integer shadows a pass left (SlArgs::det) become the doubles the finalize kernels read -- copy 0 of H,
 // slot 0 of the mask sums, of the all-ones sums and of the ELBO partials (the other copies / slots stay zero) -- and are zeroed.
@@ -2604,26 +1845,14 @@ static int launch_hist(vmr_ctx* h, int nu = -1) {
     h->f_valid = g.fuse_full != 0;
     if (g.ml) { int rc = begin_sum_a(h, h->stream); if (rc) return rc; h->a_valid = true; }
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
-    if (h->sl) {
-      const SlShape shs = sl_shape(h, false, false, true);
-      SlArgs as = sl_args(h, shs, 1, g.ml);
-      if (nu >= 0 && g.mut) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = nu; }
-      as.det = g.det ? h->det_buf : nullptr;
-      int rcs = sl_launch(h, 3, shs, as);
-      if (rcs) return rcs;
-      HIPCHK(h, hipGetLastError());
-      if ((rcs = det_fold(h))) return rcs;
-      h->h_valid = true; h->h_zero = false; h->h_reduced = false;
-      return VMR_OK;
-    }
-    const SpShape sh = sp_shape(h, false, false, true);
-    SpArgs a = sp_args(h, sh, 1, g.ml);
-    int rc = VMR_OK;
-#define LHIST(LG_)                                                                                                                     \
-  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, false, false, false, ((LG_) && KK <= SP_LONG_KMAX)>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
-             hipLaunchKernelGGL((k_rho_sp<KK, false, false, false, ((LG_) && KK <= SP_LONG_KMAX)>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g))
-    if (h->long_steps) { LHIST(true); } else { LHIST(false); }
-#undef LHIST
+    const SlShape shs = sl_shape(h, false, false, true);
+    SlArgs as = sl_args(h, shs, 1, g.ml);
+    if (nu >= 0 && g.mut) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = nu; }
+    as.det = g.det ? h->det_buf : nullptr;
+    int rcs = sl_launch(h, 3, shs, as);
+    if (rcs) return rcs;
+    HIPCHK(h, hipGetLastError());
+    if ((rcs = det_fold(h))) return rcs;
   } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
     HistArgs a{h->X, h->rho, h->Hg, 1};
@@ -2701,9 +1930,8 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     const int nh = h->h_reduced ? 1 : NH;
     const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
     hipLaunchKernelGGL(k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
-                       h->slotF, h->lutg, (h->sparse && !h->sl) ? h->Fg : nullptr, h->fin_g, (h->sparse && h->sl) ? h->nu_acc : nullptr, nh,
+                       h->slotF, h->lutg, nullptr, h->fin_g, h->sparse ? h->nu_acc : nullptr, nh,
                        with_phi ? 1 : 0, consume, g);
-    h->ftab_valid = h->sparse && with_phi;
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
     if (consume) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
   }
@@ -2737,44 +1965,20 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
     if (!g.two_pass) HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));   // rebuilt from the new rho
   }
   if (mode != 2) h->h_zero = false;
-  if (h->sparse && !h->sl && mode != 2) {
-    if (!h->ftab_valid) {
-      const int by = std::max(1, std::min(64, (g.Y * g.Mp + 255) / 256));
-      hipLaunchKernelGGL(k_build_f, dim3(g.L, by), dim3(256), 0, h->stream, h->par, h->Fg, g);
-      HIPCHK(h, hipGetLastError());
-    }
-    h->ftab_valid = false;   // the nu update that follows changes the weights
-  }
   // sorted lists with mutuality: the pass that builds H finishes nu itself -- no finalize launch on plain sweeps
-  const bool nu_in_pass = h->sparse && h->sl && g.mut && mode != 2 && (commit_nu || raw_nu);
+  const bool nu_in_pass = h->sparse && g.mut && mode != 2 && (commit_nu || raw_nu);
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
     const int sum_a = (g.ml && do_hist) ? 1 : 0;   // (two passes: the statistics pass that follows sums the lists)
     if (mode != 2) h->a_valid = false;
     if (sum_a) { if ((rc = begin_sum_a(h, h->stream))) return rc; h->a_valid = true; }
-    if (h->sl) {
-      const SlShape shs = sl_shape(h, mode != 2, mode != 0, do_hist != 0);
-      SlArgs as = sl_args(h, shs, do_hist, sum_a);
-      if (nu_in_pass && do_hist) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = commit_nu ? 1 : 0; }
-      as.det = g.det ? h->det_buf : nullptr;
-      if ((rc = sl_launch(h, mode, shs, as))) return rc;
-      if ((rc = det_fold(h))) return rc;
-    } else {
-    const SpShape sh = sp_shape(h, mode != 2, mode != 0, do_hist != 0);
-    SpArgs s = sp_args(h, sh, do_hist, sum_a);
-#define LSP2(MUT_, UPD_, ELB_, LG_)                                                            \
-  DISPATCH_K(g.K, if ((rc = grid_per_layer(h, k_rho_sp<KK, MUT_, UPD_, ELB_, ((LG_) && KK <= SP_LONG_KMAX)>, sh.smem, &s.Gl, sp_grid_cap(g, sh.tpb), sh.tpb))) return rc; \
-             hipLaunchKernelGGL((k_rho_sp<KK, MUT_, UPD_, ELB_, ((LG_) && KK <= SP_LONG_KMAX)>), dim3(g.L * s.Gl), dim3(sh.tpb), sh.smem, h->stream, s, g))
-#define LSP(MUT_, UPD_, ELB_) do { if (h->long_steps) { LSP2(MUT_, UPD_, ELB_, true); } else { LSP2(MUT_, UPD_, ELB_, false); } } while (0)
-    if (g.mut) {
-      if (mode == 0) { LSP(true, true, false); } else if (mode == 1) { LSP(true, true, true); } else { LSP(true, false, true); }
-    } else {
-      if (mode == 0) { LSP(false, true, false); } else if (mode == 1) { LSP(false, true, true); } else { LSP(false, false, true); }
-    }
-#undef LSP
-#undef LSP2
-    }
+    const SlShape shs = sl_shape(h, mode != 2, mode != 0, do_hist != 0);
+    SlArgs as = sl_args(h, shs, do_hist, sum_a);
+    if (nu_in_pass && do_hist) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = commit_nu ? 1 : 0; }
+    as.det = g.det ? h->det_buf : nullptr;
+    if ((rc = sl_launch(h, mode, shs, as))) return rc;
+    if ((rc = det_fold(h))) return rc;
   } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
 #define LRHO(MUT_, UPD_, ELB_)                                                                  \
@@ -2794,7 +1998,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
     if (g.two_pass && (rc = launch_hist(h, nu_in_pass ? (commit_nu ? 1 : 0) : -1))) return rc;   // wide reporter dimension: second pass rebuilds H
   }
   HIPCHK(h, hipGetLastError());
-  if (nu_in_pass || (h->sparse && h->sl && mode != 2 && !g.mut)) {
+  if (nu_in_pass || (h->sparse && mode != 2 && !g.mut)) {
     // nu is done (or there is none): the finalize kernel only assembles an ELBO
     if (mode != 0 && (rc = launch_fin_rho(h, 0, 1, 1))) return rc;
   } else if (mode != 0 || commit_nu) {
@@ -2875,7 +2079,6 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
   h->ncu = prop->multiProcessorCount;
   h->serial = getenv("VMR_SERIAL") != nullptr;
   h->use_graphs = getenv("VMR_GRAPH") != nullptr;   // off by default, see vmr_ctx::graphs
-  { const char* lf = getenv("VMR_LISTS"); h->sl = (lf && !strcmp(lf, "steps")) ? 0 : 1; }
   { const char* dv = getenv("VMR_DETERMINISTIC"); g.det = (dv && atoi(dv) != 0) ? 1 : 0; g.det_sh = 0; g.det_shr = 0; }   // sorted report lists unless the older step layout is asked for
   const size_t rows = (size_t)L * N * N;
   CK(hipMalloc(&h->cov, rows));
@@ -2929,58 +2132,6 @@ int scan_u32(vmr_ctx* h, unsigned* a, unsigned* bsum, size_t n) {
   return VMR_OK;
 }
 
-// Report lists from tie-major entries.  rp [L][T+1]: per-tie report counts (overwritten by their scan); nl[l]: reports of
-// layer l; fill(l, rp_l, etmp): writes layer l's entries tie-major (tie t's at rp_l[t], reporters ascending) into etmp --
-// or etmp_all already holds every layer's (layer l at offset sum of nl[<l]).
-template <class Fill>
-static int place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, Fill&& fill) {
-  Geo& g = h->g;
-  const int L = g.L;
-  const size_t T = (size_t)g.N * g.N, n = T + 1, NS = (T + 63) / 64, n2 = 2 * NS + 1, rows = (size_t)L * T;
-  const unsigned sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
-  unsigned* bsum = nullptr;
-  CK(hipMalloc(&bsum, (std::max(n, n2) + 2047) / 2048 * 4));
-  CK(hipMalloc(&h->rs, (size_t)L * n2 * 4));
-  // slot offsets of the steps (full rounds + rest, see k_sp_plan), then the per-tie offsets of the tie-major entries
-  for (int l = 0; l < L; ++l) {
-    unsigned* rpl = rp + (size_t)l * n;
-    unsigned* rsl = h->rs + (size_t)l * n2;
-    hipLaunchKernelGGL(k_sp_plan, dim3(sgrid), dim3(256), 0, h->stream, rpl, rsl, g);
-    int rc;
-    if ((rc = scan_u32(h, rsl, bsum, n2)) || (rc = scan_u32(h, rpl, bsum, n))) { (void)hipFree(bsum); return rc; }
-  }
-  CK(hipStreamSynchronize(h->stream));
-  std::vector<unsigned> slots(L);   // slots per layer (reports + padding)
-  for (int l = 0; l < L; ++l) CK(hipMemcpy(&slots[l], h->rs + (size_t)l * n2 + 2 * NS, 4, hipMemcpyDeviceToHost));
-  std::vector<unsigned long long> eb(L);
-  h->n_slots = 0;
-  for (int l = 0; l < L; ++l) {
-    eb[l] = h->n_slots; h->n_slots += slots[l];
-    if ((double)slots[l] < (double)nl[l]) { (void)hipFree(bsum); return fail(nullptr, VMR_EINVAL, "more than 2^32 report slots in one layer"); }
-  }
-  CK(hipMalloc(&h->ebase, (size_t)L * 8));
-  CK(hipMemcpyAsync(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice, h->stream));
-  CK(hipMalloc(&h->E, ((size_t)h->n_slots + 64) * 4));
-  if (!h->Qt) { CK(hipMalloc(&h->Qt, rows * 4)); CK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream)); }
-  unsigned* etmp = nullptr;   // one layer's entries in tie-major order
-  if (!etmp_all) {
-    unsigned long long nlmax = 0;
-    for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
-    CK(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
-  }
-  unsigned long long off = 0;
-  for (int l = 0; l < L; ++l) {
-    unsigned* src = etmp_all ? etmp_all + off : etmp;
-    if (!etmp_all) fill(l, rp + (size_t)l * n, etmp);
-    hipLaunchKernelGGL(k_sp_round, dim3(sgrid), dim3(256), 0, h->stream, rp + (size_t)l * n, h->rs + (size_t)l * n2, src, h->E + eb[l], g);
-    off += nl[l];
-  }
-  CK(hipGetLastError());
-  CK(hipStreamSynchronize(h->stream));   // (eb lives on the host stack of the caller's frame: copied by now)
-  if (etmp) CK(hipFree(etmp));
-  CK(hipFree(bsum));
-  return VMR_OK;
-}
 
 // mask lists for partial rows that hold few reporters (self-reporter masks: two per row), from the bit-packed words
 static int mask_lists_from_words(vmr_ctx* h) {
@@ -3075,14 +2226,12 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
   const int L = g.L, K = g.K;
   g.ml = (h->sparse && h->rq) ? 1 : 0;
-  h->long_steps = h->sparse && (double)h->nnz >= 8.0 * (double)g.L * (double)g.N * (double)g.N;
-  if (const char* e = getenv("VMR_LONG")) h->long_steps = h->sparse && atoi(e) != 0;
   // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
   g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
   g.yt = 0;
   g.two_pass = 0;
   size_t need = 0;
-  if (h->sparse && h->sl) {
+  if (h->sparse) {
     // Sorted lists: the populous levels of F (read) and H (float atomics) in LDS, shared by all waves of a workgroup; no per-wave
     // LDS at all.  One pass per sweep when every level of both fits at >= 16 waves per CU (or the levels beyond hold under 0.1 %
     // of the reports), else the rho pass keeps F and a statistics pass rebuilds H (two passes over the entries).
@@ -3144,49 +2293,6 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
     { const int t = env_i("VMR_ST_TPB", h->st_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->st_tpb = t; }
     for (int v = 0; v < 4; ++v) need = std::max(need, sl_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
-    CK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
-  } else if (h->sparse) {
-    // Report lists: both tables want the populous levels in LDS ([level][Mp][K] doubles each) beside 64 K doubles per
-    // wave, with enough waves per CU to hide latency (no barrier in the step loop, so big workgroups share one copy of
-    // the tables).  If only a few levels of each fit in one pass, H is rebuilt by a second, statistics-only pass.
-    auto env_i = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-    const int want = std::max(1, std::min(g.Y, env_i("VMR_LEVELS", 12)));
-    auto waves = [&](int tpb, int yt, int hc, bool upd, bool hist) {   // resident waves per CU: LDS and register limits
-      const size_t b = shmem_sp(g, tpb, yt, hc, upd, false, hist);
-      if (b > SP_LDS_MAX) return 0;
-      const int nw = tpb / 64, wgs = std::min((int)(SP_LDS_MAX / b), (SP_WPE * 4) / nw);
-      return wgs * nw;
-    };
-    auto best = [&](bool upd, bool hist, int min_waves, int& lv_out, int& tpb_out) {   // most levels at >= min_waves per CU
-      for (int lv = want; lv >= 1; --lv) {
-        int bw = 0, bt = 256;
-        for (int tpb : {1024, 512, 256}) { const int w = waves(tpb, upd ? lv : 0, hist ? lv : 0, upd, hist); if (w > bw) { bw = w; bt = tpb; } }
-        if (bw >= min_waves) { lv_out = lv; tpb_out = bt; return true; }
-      }
-      return false;
-    };
-    int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
-    const bool one = best(true, true, 16, lv1, t1);
-    if (one && lv1 >= std::min(want, 4)) { g.yt = g.hc = lv1; h->sp_tpb = t1; }
-    else {
-      g.two_pass = 1;
-      if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
-      if (!best(false, true, 16, lvh, th) && !best(false, true, 4, lvh, th)) { lvh = 0; th = 256; }
-      g.yt = lvr; g.hc = lvh; h->sp_tpb = std::min(tr, th);
-    }
-    // small datasets (a Karnataka village: 1640 steps): smaller workgroups, so that the steps spread over every CU --
-    // a sweep there is bound by the latency of its kernels, not by their throughput
-    {
-      const long long NS = ((long long)g.N * g.N + 63) / 64;
-      while (h->sp_tpb > 64 && NS * L < (long long)h->ncu * (h->sp_tpb / 64)) h->sp_tpb >>= 1;
-    }
-    // experiments: force the shape
-    if (getenv("VMR_TWO_PASS")) g.two_pass = env_i("VMR_TWO_PASS", 0) ? 1 : 0;
-    g.yt = std::max(0, std::min(g.Y, env_i("VMR_YT", g.yt)));
-    g.hc = std::max(0, std::min(g.Y, env_i("VMR_HC", g.hc)));
-    { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
-    for (int v = 0; v < 4; ++v) need = std::max(need, sp_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
-    CK(hipMalloc(&h->Fg, (size_t)L * g.Y * g.Mp * K * 8));
   } else {
     if (shmem_rho(g, true, false) > 80000) {
       g.two_pass = 1;
@@ -3214,7 +2320,7 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   if (g.det) {
     // VMR_DETERMINISTIC=1 (sorted report lists only): see SlArgs::det.  The fixed point of the count-weighted sums leaves
     // room for the sum of all counts.
-    if (!(h->sparse && h->sl)) return fail(nullptr, VMR_EINVAL, "VMR_DETERMINISTIC=1 needs the sorted report lists (a sparse tensor with M <= 8192, counts <= 2047)");
+    if (!h->sparse) return fail(nullptr, VMR_EINVAL, "VMR_DETERMINISTIC=1 needs the report lists (a sparse tensor with M <= 8192, counts <= 2047)");
     unsigned long long sx = 0;
     CK(hipMemcpyAsync(&sx, h->sumx, 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
@@ -3237,15 +2343,10 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     // the constants C[l][y][m] = sum of the counts per (mirror count, reporter): one statistics launch in count mode
     CK(hipMalloc(&h->Cg, (size_t)L * g.Y * g.Mp * 8));
     int rc = VMR_OK;
-    if (h->sl) {
+    {
       const SlShape sh = sl_shape(h, false, false, true);
       SlArgs a = sl_args(h, sh, 2);
       rc = sl_launch(h, 3, sh, a);
-    } else {
-      const SpShape sh = sp_shape(h, false, false, true);
-      SpArgs a = sp_args(h, sh, 2);
-      DISPATCH_K(g.K, rc = grid_per_layer(h, k_rho_sp<KK, false, false, false>, sh.smem, &a.Gl, sp_grid_cap(g, sh.tpb), sh.tpb);
-                 if (rc == VMR_OK) hipLaunchKernelGGL((k_rho_sp<KK, false, false, false>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g));
     }
     if (rc != VMR_OK) { g_create_err = h->err; return rc; }
     CK(hipGetLastError());
@@ -3290,7 +2391,7 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
   const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
   const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
   // 13-bit reporter field; the sorted lists hold counts <= 2047 and (max count + 1) * Mp <= 2^20 table rows, the step layout counts <= 63
-  const bool can_list = g.Mp <= 8192 && (h->sl ? (xm <= SL_XMAX && (size_t)(xm + 1) * g.Mp <= SL_YM_ROWS) : xm <= ENT_CMAX);
+  const bool can_list = g.Mp <= 8192 && xm <= SL_XMAX && (size_t)(xm + 1) * g.Mp <= SL_YM_ROWS;
   if (!force_dense && can_list) {
     unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
     CK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
@@ -3317,17 +2418,15 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
       auto fill_layer = [&](int l, const unsigned* rpl, unsigned* etmp) {
         if (g.mut)
           hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, h->sl, g);
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
         else
           hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, h->sl, g);
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
       };
-      if (h->sl) {
+      {
         const SlFill ff = fill_layer;
         rc = sl_place_entries(h, rp, nl, nullptr, &ff);
         if (!rc) rc = sl_finish(h);
-      } else {
-        rc = place_entries(h, rp, nl, nullptr, fill_layer);
       }
       if (!rc) rc = mask_lists_from_words(h);
       if (!rc && !getenv("VMR_KEEP_X")) { CK(hipFree(h->X)); h->X = nullptr; }   // the lists replace the dense tensor
@@ -3414,15 +2513,14 @@ __global__ void k_coo_class(const unsigned* __restrict__ cx, const unsigned* __r
 template <bool MUT>
 __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const unsigned* __restrict__ vx, long long nx,
                               const unsigned long long* __restrict__ kr, long long nr /* < 0: all ones */, int N, int Mp,
-                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad,
-                              int sl) {
+                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad) {
   unsigned long long s = 0;
   unsigned mx = 0;
   const unsigned long long T = (unsigned long long)N * N;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (long long)gridDim.x * blockDim.x) {
     const unsigned long long key = kx[e], tie = key >> 13, l = tie / T, t = tie - l * T, i = t / N, j = t - i * N;
     const unsigned m = (unsigned)(key & 0x1fffu), x = vx[e];
-    if (x == 0u || x > (sl ? SL_XMAX : ENT_CMAX)) { atomicOr(bad, 4); continue; }
+    if (x == 0u || x > SL_XMAX) { atomicOr(bad, 4); continue; }
     s += x; mx = max(mx, x);
     const unsigned long long tm = l * T + j * N + i;
     unsigned y = 0;
@@ -3432,8 +2530,7 @@ __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const u
       if (nr < 0 || coo_find(kr, nr, COO_KEY(tm, m)) >= 0) atomicAdd(&Qt[tm], x);   // R[mirror, m] X[this, m]
     }
     const unsigned inr = (nr < 0 || coo_find(kr, nr, key) >= 0) ? 1u : 0u;
-    etmp[e] = sl ? ((y * (unsigned)Mp + m) | (inr << 20) | (x << 21))
-                 : ((y * (unsigned)Mp + m) | (inr << 19) | ((unsigned)(t & 63) << 20) | (x << 26));
+    etmp[e] = (y * (unsigned)Mp + m) | (inr << 20) | (x << 21);   // (sweep_sl.h)
   }
   if (s) atomicAdd(sumx, s);
   if (mx) atomicMax(xmax, mx);
@@ -3561,8 +2658,8 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   CKC(hipMalloc(&etmp, ((size_t)nx + 64) * 4));
   CKC(hipMalloc(&h->Qt, rows * 4));
   CKC(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev, h->sl);
-  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev, h->sl);
+  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
+  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
   CKC(hipGetLastError());
   CKC(hipStreamSynchronize(h->stream));
   int bad = 0;
@@ -3573,8 +2670,7 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     cleanup();
     return fail(nullptr, VMR_EINVAL, (bad & 1) ? "a subscript lies outside (L, N, N, M)"
                                    : (bad & 2) ? "duplicate (l, i, j, m) subscripts"
-                                               : (h->sl ? "counts must lie in [1, 2047] for the report lists"
-                                                        : "counts must lie in [1, 63] for the report lists (use vmr_create for larger counts)"));
+                                               : "counts must lie in [1, 2047] for the report lists");
   }
   unsigned xmv = 0;
   if ((rc = create_state(h, &xmv))) { cleanup(); return rc; }
@@ -3593,12 +2689,12 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     CKC(e1);
     for (int l = 0; l < L; ++l) nl[l] = st[l + 1] - st[l];
   }
-  if (h->sl && (size_t)(xmv + 1) * g.Mp > SL_YM_ROWS) {
+  if ((size_t)(xmv + 1) * g.Mp > SL_YM_ROWS) {
     cleanup();
     return fail(nullptr, VMR_EINVAL, "(largest count + 1) * M exceeds the 2^20 table rows of the report lists");
   }
-  if (h->sl) { rc = sl_place_entries(h, cx, nl, etmp, nullptr); if (!rc) rc = sl_finish(h); }
-  else rc = place_entries(h, cx, nl, etmp, [](int, const unsigned*, unsigned*) {});
+  rc = sl_place_entries(h, cx, nl, etmp, nullptr);
+  if (!rc) rc = sl_finish(h);
   if (rc) { cleanup(); return rc; }
   // the mask: all ones needs nothing; partial rows become mask lists when they are short, bit-packed words otherwise
   if (nr >= 0 && h->n_partial > 0) {
@@ -3661,7 +2757,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Fg, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3764,7 +2860,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   h->h_valid = false;
   h->f_valid = false;
   h->a_valid = false;
-  h->ftab_valid = false; h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
+  h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   return VMR_OK;
 }
@@ -3893,12 +2989,12 @@ int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, 
 // Handles of another kind than the first (K, mutuality, mask kind, report lists in one pass) run their loops one by one.
 static bool batch_steady(const vmr_ctx* h) {
   const Geo& g = h->g;
-  return h->have_state && !h->restored && h->sparse && h->sl && !g.two_pass && h->h_valid && !h->h_reduced && !h->h_zero &&
+  return h->have_state && !h->restored && h->sparse && !g.two_pass && h->h_valid && !h->h_reduced && !h->h_zero &&
          h->f_valid == (g.fuse_full != 0) && (!g.ml || h->a_valid) && !h->prof;
 }
 static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
   // (a sweep of such a handle is k_fin_gamma + the pass, + k_fin_rho with an ELBO: the pass sums rho over the mask itself)
-  return h->sparse && h->sl && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
+  return h->sparse && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
          h->g.K == h0->g.K && h->g.mut == h0->g.mut && (h->all_full != 0) == (h0->all_full != 0);
 }
 namespace {
@@ -4113,7 +3209,7 @@ int vmr_sweep_local(vmr_handle h, int want_elbo, double* out3) {
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;
   if ((rc = launch_rho(h, want_elbo ? 1 : 0, false, true))) return rc;   // rho updated, nu NOT committed
-  if (!want_elbo && !(h->sparse && h->sl)) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
+  if (!want_elbo && !h->sparse) {   // launch_rho skipped the finalize kernel: run it for the raw pieces only
     if ((rc = launch_fin_rho(h, 0, 0))) return rc;   // (sorted lists: the pass left the raw nu sum itself)
   }
   double v[4];
@@ -4141,7 +3237,7 @@ int vmr_sweep_local_dev(vmr_handle h, int want_elbo, double* out3_dev) {
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;
   if ((rc = launch_rho(h, want_elbo ? 1 : 0, false, true))) return rc;
-  if (!want_elbo && !(h->sparse && h->sl) && (rc = launch_fin_rho(h, 0, 0))) return rc;
+  if (!want_elbo && !h->sparse && (rc = launch_fin_rho(h, 0, 0))) return rc;
   HIPCHK(h, hipMemcpyAsync(out3_dev, h->elbo_dev + 1, 24, hipMemcpyDeviceToDevice, h->stream));
   return VMR_OK;
 }
@@ -4251,7 +3347,7 @@ int vmr_restore(vmr_handle h) {
   const Geo& g = h->g;
   HIPCHK(h, hipMemcpyAsync(h->rho, h->rho_snap, (size_t)g.L * g.N * g.N * g.K * 8, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->par, h->par_snap, h->par_doubles * 8, hipMemcpyDeviceToDevice, h->stream));
-  h->h_valid = false; h->f_valid = false; h->a_valid = false; h->ftab_valid = false; h->h_zero = false;
+  h->h_valid = false; h->f_valid = false; h->a_valid = false; h->h_zero = false;
   h->restored = true;   // the log prior on the device is the LAST realisation's: reading is fine, sweeping is not
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
@@ -4361,7 +3457,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
     // entries (without the rounds' padding); step pointers: two per 64 ties in the step layout, one in the sorted lists
-    const double E = 4.0 * (double)h->nnz, RP = 4.0 * ((h->sl ? 1.0 : 2.0) * ties / 64.0 + g.L);
+    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties / 64.0 + g.L);
     const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {

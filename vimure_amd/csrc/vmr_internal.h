@@ -86,8 +86,6 @@ struct vmr_ctx {
   int sparse = 0;
   unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
   unsigned* rs = nullptr;      // [L][N*N/64+1] first entry of every 64-tie step, relative to ebase[l]
-  double* Fg = nullptr;        // [L][Y][Mp][K] per-report factors of the rho update (k_build_f / k_fin_gamma)
-  bool ftab_valid = false;     // Fg matches the current parameters
   double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
   int sp_tpb = 256;            // threads per workgroup of the report-list passes that update rho or reduce the ELBO
   int st_tpb = 256;            // ... of the statistics-only pass (a lighter variant: bigger workgroups)
@@ -96,9 +94,8 @@ struct vmr_ctx {
   unsigned long long nnz = 0;  // non-zero counts in X
   unsigned long long n_slots = 0;   // entry slots of the report lists: nnz + the padding of the full rounds
   int all_full = 0;            // every mask row is all ones
-  // sorted report lists (sweep_sl.h): the default list format.  rho, logpr and the per-tie arrays below are then stored BY
-  // SORTED POSITION; perm translates at the boundary (vmr_set_state, vmr_get_state, vmr_readout, vmr_sample)
-  int sl = 0;
+  // report lists (sweep_sl.h): rho, logpr and the per-tie arrays below are stored BY SORTED POSITION; perm translates at the
+  // boundary (vmr_set_state, vmr_get_state, vmr_readout, vmr_sample)
   unsigned* perm = nullptr;    // [L][NS*64] position -> tie (0xffffffff past the last tie)
   unsigned* sy = nullptr;      // [L][NS] highest mirror-count level of a step's reports
   uint8_t* cls_p = nullptr;    // [L][T] rcls by position (null when every row is all ones)
@@ -131,7 +128,6 @@ struct vmr_ctx {
   bool h_valid = false;        // H matches the current rho
   double* slotF = nullptr;     // [L][NSLOT][K]: sum of the new rho over ties whose mask row is all ones (rho pass)
   bool f_valid = false;        // slotF matches the current rho
-  bool long_steps = false;     // report lists with >= 8 reports per tie on average: the LONG variants of k_rho_sp
   bool a_valid = false;        // slotA holds the mask-list sums of the current rho (summed by the last rho / statistics pass)
   bool a_zero = true;          // slotA is known to be all zero
   bool h_reduced = false;      // the NH copies of H are folded into copy 0 (what the finalize kernels read)
