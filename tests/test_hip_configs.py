@@ -137,7 +137,7 @@ def test_config3_full_size_fit_stops_where_the_oracle_stops():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mode", ["default", "short_step_kernels", "one_pass_two_levels", "two_passes", "no_lds_levels"])
+@pytest.mark.parametrize("mode", ["default", "small_workgroups", "one_pass_two_levels", "two_passes", "no_lds_levels"])
 def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): a level of the factor
     table F or of the statistics H is 24 KB here, so only a few levels of each fit in LDS beside each other.  The engine
@@ -147,7 +147,7 @@ def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
-    env = {"short_step_kernels": {"VMR_LONG": "0"},   # (19 reports per tie: the LONG variants of k_rho_sp by default)
+    env = {"small_workgroups": {"VMR_TPB": "128", "VMR_ST_TPB": "256"},   # (more workgroups, fewer waves behind each ticket counter)
            "one_pass_two_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "2", "VMR_HC": "2"},
            "two_passes": {"VMR_TWO_PASS": "1", "VMR_YT": "5", "VMR_HC": "5"},
            "no_lds_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "0", "VMR_HC": "0", "VMR_TPB": "256"}}.get(mode, {})
@@ -177,8 +177,8 @@ def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
 
 @pytest.mark.parametrize("mask", ["ones", "random"])
 def test_long_steps_two_categories(mask, monkeypatch):
-    """Many reports per tie (here 19 of M = 64 reporters, K = 2): steps of more full rounds than prefetched trips, i.e. the LONG
-    variants of k_rho_sp with their ring of loads -- against the coordinate-list oracle, mutuality on, with and without mask."""
+    """Many reports per tie (here 19 of M = 64 reporters, K = 2): steps of more rounds than the straight-line bodies hold, i.e. the
+    sweep kernel's general body with its ring of loads -- against the coordinate-list oracle, mutuality on, with and without mask."""
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     monkeypatch.setenv("VMR_FORMAT", "sparse")   # (at this density the dense tiles would be chosen)

@@ -41,12 +41,12 @@ def one(case, g):
     if fmt != "auto":
         env["VMR_FORMAT"] = fmt
     if g.rand() < 0.3:
-        env["VMR_LONG"] = str(int(g.rand() < 0.5))
+        env["VMR_ST_TPB"] = str(int(g.choice([64, 256, 1024])))
     if g.rand() < 0.3:
         env.update({"VMR_TWO_PASS": str(int(g.rand() < 0.5)), "VMR_YT": str(int(g.randint(0, 4))), "VMR_HC": str(int(g.randint(0, 4)))})
     if g.rand() < 0.3:
         env["VMR_TPB"] = str(int(g.choice([64, 128, 256, 512, 1024])))
-    old = {k: os.environ.get(k) for k in ("VMR_FORMAT", "VMR_LONG", "VMR_TWO_PASS", "VMR_YT", "VMR_HC", "VMR_TPB")}
+    old = {k: os.environ.get(k) for k in ("VMR_FORMAT", "VMR_ST_TPB", "VMR_TWO_PASS", "VMR_YT", "VMR_HC", "VMR_TPB")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
