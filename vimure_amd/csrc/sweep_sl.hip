@@ -113,11 +113,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
-  // deterministic mode: the integer shadows (SlArgs::det)
-  unsigned long long* const dH = a.det ? a.det + (size_t)l * g.Y * Mp * K : nullptr;
-  unsigned long long* const dA = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)l * g.W * 64 * K : nullptr;
-  unsigned long long* const dF = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)l * K : nullptr;
-  unsigned long long* const dR = a.det ? a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)g.L * K : nullptr;   // [4], then the nu share
+  // deterministic mode: the integer shadows (SlArgs::det), located where they are used (nothing of this lives across the step loop)
+  auto det_H = [&]() SL_INL { return a.det + (size_t)l * g.Y * Mp * K; };
+  auto det_A = [&]() SL_INL { return a.det + (size_t)g.L * g.Y * Mp * K + (size_t)l * g.W * 64 * K; };
+  auto det_F = [&]() SL_INL { return a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)l * K; };
+  auto det_R = [&]() SL_INL { return a.det + (size_t)g.L * g.Y * Mp * K + (size_t)g.L * g.W * 64 * K + (size_t)g.L * K; };   // [4], then the nu share
   const unsigned* rsl = a.rs + (size_t)l * (NS + 1);
   const unsigned* syl = a.sy + (size_t)l * NS;
   const unsigned* El = a.E + a.ebase[l];
@@ -146,9 +146,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   unsigned* tick = reinterpret_cast<unsigned*>(smem + off); off += 16;
   if (tid == 0) { tick[0] = 2u * (unsigned)nw; tick[1] = 0u; }   // ([1]: some step of this workgroup added a deficit)
   auto step_of = [&](unsigned t) SL_INL -> long long { return (long long)gb + (long long)t * Gl_; };
-  unsigned fixed_t = (unsigned)(2 * nw + wv);   // (deterministic mode: tickets wv, nw + wv, 2 nw + wv, ... -- a fixed share)
+  // (deterministic mode: a workgroup is one wave, so the counter hands it 0, 1, 2, ... -- a fixed share, in order)
   auto draw = [&]() SL_INL -> long long {   // this wave's next ticket (one LDS atomic by lane 0)
-    if (a.det) { const unsigned t = fixed_t; fixed_t += (unsigned)nw; return step_of(t); }
     unsigned t = 0u;
     if (lane == 0) t = atomicAdd(tick, 1u);
     return step_of((unsigned)__builtin_amdgcn_readfirstlane((int)t));
@@ -558,8 +557,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             if (irr) atomicAdd(&Hc[row], dx * dfc);   // (wave-uniform: some tie of the step does not sum to 1)
             if (__any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
               if (fr && x != 0u) {   // table by the grid's last workgroup (nu_far).
-                if (dH) {
-                  unsigned long long* d = dH + (size_t)ym * K;
+                if (a.det) {
+                  unsigned long long* d0 = a.det;
+                  asm volatile("" : "+s"(d0));   // (keeps this address arithmetic inside the rare branch: hoisted, it cost every variant ten registers)
+                  unsigned long long* d = d0 + (size_t)l * g.Y * Mp * K + (size_t)ym * K;
 #pragma unroll
                   for (int k = 1; k < K; ++k) atomicAdd(&d[k], det_fx((double)x * r[k], g.det_sh));
                   if (dfc != 0.0) atomicAdd(&d[0], det_fx((double)x * dfc, g.det_sh));
@@ -639,7 +640,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     }
     a0p = block_sum_n(a0p, red);
     if (tid == 0) {
-      if (dR) atomicAdd(&dR[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
+      if (a.det) atomicAdd(&det_R()[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
     }
   }
   // the flush: every wave but the first when the first draws the ticket (it then has nothing else of its own outstanding)
@@ -652,7 +653,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       const double v = Hc[q];
       if (v != 0.0) {
         const int k = q / (int)hcm, ym = q - k * (int)hcm;
-        if (dH) atomicAdd(&dH[(size_t)ym * K + k], det_fx(v, g.det_sh)); else atomicAdd(&Hl[(size_t)ym * K + k], v);
+        if (a.det) atomicAdd(&det_H()[(size_t)ym * K + k], det_fx(v, g.det_sh)); else atomicAdd(&Hl[(size_t)ym * K + k], v);
       }
     }
   }
@@ -660,7 +661,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
     for (int q = tid - f0; q < g.M * K; q += nthr - f0) {
       const double v = As[q];
-      if (v != 0.0) { if (dA) atomicAdd(&dA[q], det_fx(v, DET_SH_A)); else atomicAdd(&out[q], v); }
+      if (v != 0.0) { if (a.det) atomicAdd(&det_A()[q], det_fx(v, DET_SH_A)); else atomicAdd(&out[q], v); }
     }
   }
   if (nu_here) {
@@ -728,7 +729,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       far = block_sum_n(far, red);
       if (tid == 0) {
         double tot = far;   // + every workgroup's share (device-scope read)
-        if (dR) { tot += det_back(atomicAdd(&dR[4], 0ull), g.det_sh); dR[4] = 0ull; } else tot += atomicAdd(&a.nu_acc[0], 0.0);
+        if (a.det) { unsigned long long* dR = det_R(); tot += det_back(atomicAdd(&dR[4], 0ull), g.det_sh); dR[4] = 0ull; } else tot += atomicAdd(&a.nu_acc[0], 0.0);
         for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
         a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
         a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
@@ -746,7 +747,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       double v = block_sum_n(accF[k], red);
-      if (tid == 0) { if (dF) atomicAdd(&dF[k], det_fx(v, DET_SH_A)); else atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v); }
+      if (tid == 0) { if (a.det) atomicAdd(&det_F()[k], det_fx(v, DET_SH_A)); else atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v); }
     }
   }
   if (ELBO) {
@@ -755,7 +756,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     double v3 = block_sum_n(e_q, red);
     if (tid == 0) {
       double* out = a.slotR + (size_t)(bx % NSLOT) * 4;
-      if (dR) { atomicAdd(&dR[1], det_fx(v1, g.det_shr)); atomicAdd(&dR[2], det_fx(v2, g.det_shr)); atomicAdd(&dR[3], det_fx(v3, g.det_shr)); }
+      if (a.det) { unsigned long long* dR = det_R(); atomicAdd(&dR[1], det_fx(v1, g.det_shr)); atomicAdd(&dR[2], det_fx(v2, g.det_shr)); atomicAdd(&dR[3], det_fx(v3, g.det_shr)); }
       else { atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3); }
     }
   }

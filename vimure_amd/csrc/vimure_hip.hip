@@ -1224,7 +1224,9 @@ __device__ __forceinline__ double h_sum(double* Hl0, size_t, size_t idx) {   // 
 }
 __device__ __forceinline__ double h_at(const double* Hl0, size_t, size_t idx) { return Hl0[idx]; }
 
-#define FIN_TPB 1024
+#ifndef FIN_TPB
+#define FIN_TPB 512   // (1024: 128 registers, 16-33 spilled, +2 us per launch; 256: +5 us)
+#endif
 #define FG_G 16   // workgroups per layer of k_fin_gamma: each owns a range of reporters
 __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) {   // result valid in thread 0
   v = wave_sum(v);
@@ -1250,10 +1252,11 @@ __device__ __forceinline__ double block_sum_fin(double v, double* red /*16*/) { 
 // the ticket, acquire after it).  One workgroup per layer (rounds 1-2) kept 4 of 256 CUs busy for 25 us per sweep.
 // consume = 1 (fused sweep): H and slotF are read for the last time here and left zeroed for the rho pass.
 // (bx: the workgroup's index in its handle's grid -- the launch's, or the handle's share of a lockstep launch, k_fin_gamma_b)
+template <bool det /*Geo::det: sums whose order would vary are integer or in slots (its own instantiation: the code costs the plain one 3 us)*/>
 __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
                                                double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
                                                int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, const Geo& g,
-                                               const int bx, const int det = 0 /*Geo::det: sums whose order would vary are integer or in slots*/) {
+                                               const int bx) {
   extern __shared__ double dyn[];   // s1[mper]: sum_{y,k} w1 H per reporter; gthn[mper]: the new G_theta
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
@@ -1478,7 +1481,11 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
 }
 __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
                                                        double* lutg, double* Fg, double* fin, double* nu_acc, int nh, int do_phi, int consume, Geo g) {
-  fin_gamma_body(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x, g.det);
+  fin_gamma_body<false>(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma_det(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
+                                                           double* lutg, double* Fg, double* fin, double* nu_acc, int nh, int do_phi, int consume, Geo g) {
+  fin_gamma_body<true>(par, Hg, Cg, slotA, slotF, lutg, Fg, fin, nu_acc, nh, do_phi, consume, g, (int)blockIdx.x);
 }
 // the finalize kernels of many small handles in one launch (vmr_fit_loop_batch): workgroup -> unit through blk_unit
 struct FinUnit {
@@ -1487,7 +1494,7 @@ struct FinUnit {
 };
 __global__ __launch_bounds__(FIN_TPB) void k_fin_gamma_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit) {
   const FinUnit& u = units[blk_unit[blockIdx.x]];
-  fin_gamma_body(u.par, u.Hg, u.Cg, u.slotA, u.slotF, u.lutg, nullptr, u.fin_g, u.nu_acc, NH, 1, 1, u.g, (int)blockIdx.x - u.fg_blk0);
+  fin_gamma_body<false>(u.par, u.Hg, u.Cg, u.slotA, u.slotF, u.lutg, nullptr, u.fin_g, u.nu_acc, NH, 1, 1, u.g, (int)blockIdx.x - u.fg_blk0);
 }
 
 // phi commit, mutuality on: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887; the cache
@@ -1929,7 +1936,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     const int consume = (with_phi && !g.two_pass) ? 1 : 0;
     const int nh = h->h_reduced ? 1 : NH;
     const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
-    hipLaunchKernelGGL(k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
+    hipLaunchKernelGGL(g.det ? k_fin_gamma_det : k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
                        h->slotF, h->lutg, nullptr, h->fin_g, h->sparse ? h->nu_acc : nullptr, nh,
                        with_phi ? 1 : 0, consume, g);
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
