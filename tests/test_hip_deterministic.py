@@ -72,3 +72,31 @@ def test_deterministic_config3_sized_run_is_bit_equal(monkeypatch):
         assert np.array_equal(np.asarray(outs[0][1][k]), np.asarray(outs[1][1][k])), k
     del net
     torch.cuda.empty_cache()
+
+
+def test_deterministic_two_pass_regime_is_bit_equal(monkeypatch):
+    """The config-5 regime (M = 1000 reporters, K = 3: a rho pass and a statistics pass per sweep, levels beyond the LDS copies)."""
+    import torch
+    from bench import draw_state
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    monkeypatch.setenv("VMR_DETERMINISTIC", "1")
+    monkeypatch.setenv("VMR_TWO_PASS", "1")
+    monkeypatch.setenv("VMR_YT", "2")
+    monkeypatch.setenv("VMR_HC", "2")
+    net = standard_sbm(N=300, M=1000, L=1, K=3, C=2, avg_degree=5.0, eta=0.5, seed=2, device="cuda:0")
+    outs = []
+    for _ in range(2):
+        eng = CaviEngine(net.X, None, K=3, mutuality=True, device=0)
+        sum_x, cov = eng.data_stats()
+        host, pr = draw_state(dict(L=1, N=300, M=1000, K=3, mutuality=True), 4, sum_x, cov)
+        eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+        eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+        e = [eng.step(1, want_elbo=True) for _ in range(4)]
+        outs.append((e, eng.get_state(rho=True)))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "rho"):
+        assert np.array_equal(np.asarray(outs[0][1][k]), np.asarray(outs[1][1][k])), k
+    del net
+    torch.cuda.empty_cache()

@@ -73,3 +73,29 @@ def test_fit_datasets_lockstep_equals_threads():
     assert a[["dataset", "layer", "seed", "iters"]].values.tolist() == b[["dataset", "layer", "seed", "iters"]].values.tolist()
     np.testing.assert_allclose(a["elbo"].values, b["elbo"].values, rtol=1e-10)
     np.testing.assert_allclose(a["nu"].values, b["nu"].values, rtol=1e-9)
+
+
+def test_lockstep_with_several_layers_and_five_categories():
+    """Units of L = 2 layers and K = 5 (the 512-thread lockstep variants), all-ones mask next to self-reporter masks of the same kind
+    only: the all-ones unit runs alone, the others together."""
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    from vimure_amd.tensor import SparseTensor
+    K = 5
+    data = [_village(48, 1, K=K, L=2), _village(60, 2, K=K, L=2), _village(36, 3, K=K, L=2)]
+    net = standard_sbm(N=40, M=12, L=2, K=K, avg_degree=4.0, eta=0.4, seed=9)
+    single = []
+    for s, (X, R) in enumerate(data):
+        eng = _engine_with_state(X, R, K, 30 + s)
+        single.append((eng.fit_loop(31, 0.1, 1), eng.get_state(rho=True)))
+        eng.close()
+    engs = [_engine_with_state(X, R, K, 30 + s) for s, (X, R) in enumerate(data)]
+    both = CaviEngine.fit_loop_batch(engs, 31, 0.1, 1)
+    for (one, st1), two, eng in zip(single, both, engs):
+        assert [r[0] for r in one[0]] == [r[0] for r in two[0]] and one[2] == two[2]
+        np.testing.assert_allclose([r[1] for r in two[0]], [r[1] for r in one[0]], rtol=1e-10)
+        st2 = eng.get_state(rho=True)
+        for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "rho"):
+            np.testing.assert_allclose(st2[k], st1[k], rtol=1e-9, atol=1e-12, err_msg=k)
+        eng.close()
+    del net
