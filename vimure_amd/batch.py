@@ -125,12 +125,14 @@ class _LockstepFit:
         return m
 
 
-def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=DEFAULT_WORKERS, keep=None, width=64):
+def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=DEFAULT_WORKERS, keep=None, width=64, on_model=None):
     """units: [(tag, Xl, Rl)].  Every (unit, seed) fit as `_fit_unit` would run it, but up to `width` units advance together: one
     engine per unit holds its data, the seeds go one after the other, and realisation r of the current seed runs on all engines
     in lockstep (vmr_fit_loop_batch: one launch per kernel and sweep for all of them).  The host's share -- the RandomState draw
     of each initial state and its upload -- runs on `workers` threads.  Returns {tag: (rows, models)} as `_fit_unit`.
-    `seconds` of a row is the wall time of its group's pass over that seed divided by the fits in it."""
+    `seconds` of a row is the wall time of its group's pass over that seed divided by the fits in it.  on_model(tag, seed, model,
+    seconds), if given, is called (on the worker threads) for every fitted model as soon as its seed is done -- with rho_f on the
+    host -- and the models are not kept."""
     eps = float(fit_kwargs.get("EPS", 1e-12))
     seeds = [int(s) for s in seeds]
     out = {}
@@ -150,7 +152,7 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
                 res = {u[0]: ([], []) for u in group}
                 for seed in seeds:
                     t0 = time.perf_counter()
-                    fits = timed("prepare", lambda: list(ex.map(lambda ue: _LockstepFit(ue[0][1], ue[0][2], K, seed, mutuality, ue[1], fit_kwargs, need_rho=keep is not None), zip(group, engs))))
+                    fits = timed("prepare", lambda: list(ex.map(lambda ue: _LockstepFit(ue[0][1], ue[0][2], K, seed, mutuality, ue[1], fit_kwargs, need_rho=keep is not None or on_model is not None), zip(group, engs))))
                     live = list(range(len(fits)))
                     drawn = [ex.submit(fits[i].draw) for i in live]   # realisation 0
                     while live:
@@ -171,6 +173,8 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
                         timed("pull", lambda: list(ex.map(end, zip(live, loops))))
                     models = timed("finish", lambda: list(ex.map(lambda f: f.finish(), fits)))
                     dt = (time.perf_counter() - t0) / max(1, len(fits))
+                    if on_model is not None:
+                        list(ex.map(lambda um: on_model(um[0][0], seed, um[1], dt), zip(group, models)))
                     for u, m in zip(group, models):
                         rows, kept = res[u[0]]
                         rows.append({"layer": u[0], "seed": seed, "elbo": float(m.maxL),
@@ -457,11 +461,13 @@ def karnataka_tables(model, X, R, village, layer, seed, running_time) -> Dict[st
 
 
 def run_karnataka(villages: Dict[str, tuple], seeds: Iterable[int] = range(1, 11), out_dir: str = None, K=2, mutuality=True,
-                  num_realisations=5, max_iter=101, device=None, workers=DEFAULT_WORKERS, **fit_kwargs) -> Dict[str, pd.DataFrame]:
+                  num_realisations=5, max_iter=101, device=None, workers=DEFAULT_WORKERS, lockstep=True, **fit_kwargs) -> Dict[str, pd.DataFrame]:
     """`karnataka.main` over many villages: villages = name -> (X [L,N,N,N], R, layer names); every layer is fitted on its own
     (L = 1) for every seed with `fit(X, R=R, K=2, seed=seed, num_realisations=5, max_iter=101)` (karnataka.py:188-191).
     With `out_dir` the four CSVs are appended as the reference does, and (village, layer, seed) rows already in the summary
-    file are skipped (its resume logic, karnataka.py:172-181).  Returns the four tables of this call."""
+    file are skipped (its resume logic, karnataka.py:172-181).  Returns the four tables of this call.  lockstep (default): the
+    (village, layer) units advance together, one launch per kernel and sweep for all of them (`fit_units_lockstep`), and each
+    model's tables are written as soon as its seed is done; lockstep=False: one unit per host thread."""
     seeds = [int(s) for s in seeds]
     done = set()
     if out_dir is not None:
@@ -487,14 +493,32 @@ def run_karnataka(villages: Dict[str, tuple], seeds: Iterable[int] = range(1, 11
                     if out_dir is not None:
                         path = os.path.join(out_dir, KARNATAKA_FILES[k])
                         df.to_csv(path, mode="a", header=not os.path.exists(path) or os.path.getsize(path) == 0, index=False)
-    jobs = []
+    def emit(village, lname, Xl, Rl, seed, m, dt):
+        tabs = karnataka_tables(m, Xl, Rl, village, lname, seed, dt)
+        with lock:
+            for k, df in tabs.items():
+                acc[k].append(df)
+                if out_dir is not None:
+                    path = os.path.join(out_dir, KARNATAKA_FILES[k])
+                    df.to_csv(path, mode="a", header=not os.path.exists(path) or os.path.getsize(path) == 0, index=False)
+    jobs, by_todo = [], {}
     for village in sorted(villages):
         X, R, lnames = (tuple(villages[village]) + (None,))[:3]
         Xd, Rd = _as_data(X, R)
         for l in range(int(Xd.shape[0])):
             lname = lnames[l] if lnames is not None else l
-            jobs.append((float(Xd.shape[1]) ** 3, lambda village=village, l=l, lname=lname, Xl=layer_of(Xd, l),
-                         Rl=layer_of(Rd, l): unit(village, l, lname, Xl, Rl)))
-    jobs.sort(key=lambda j: -j[0])
-    _run_units([j for _, j in jobs], workers)
+            Xl, Rl = layer_of(Xd, l), layer_of(Rd, l)
+            jobs.append((float(Xd.shape[1]) ** 3, lambda village=village, l=l, lname=lname, Xl=Xl, Rl=Rl: unit(village, l, lname, Xl, Rl)))
+            todo = tuple(s for s in seeds if (village, lname, s) not in done)
+            if todo:
+                by_todo.setdefault(todo, []).append(((village, lname), Xl, Rl))
+    if lockstep:
+        kw = dict(fit_kwargs, num_realisations=num_realisations, max_iter=max_iter)
+        for todo, units in by_todo.items():   # (units that share the seeds still to do advance together)
+            data = {u[0]: (u[1], u[2]) for u in units}
+            fit_units_lockstep(units, K, list(todo), mutuality, device, kw, workers=workers,
+                               on_model=lambda tag, seed, m, dt: emit(tag[0], tag[1], data[tag][0], data[tag][1], seed, m, dt))
+    else:
+        jobs.sort(key=lambda j: -j[0])
+        _run_units([j for _, j in jobs], workers)
     return {k: (pd.concat(v, ignore_index=True) if v else pd.DataFrame()) for k, v in acc.items()}
