@@ -97,12 +97,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
+    # VMR_BENCH_REHEARSE=1 (development: the N-rank code path on a box with fewer GPUs): ranks share the devices there are and
+    # talk over gloo with host tensors; the line then says so and is no N-GPU measurement
+    rehearse = bool(os.environ.get("VMR_BENCH_REHEARSE")) and world > 1
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    cdev = "cpu" if rehearse else dev   # where the collectives' tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     if world > 1 and rank == 0:
         print(f"bench.py: RCCL world size {dist.get_world_size()} (backend {dist.get_backend()}), one rank per GPU", file=sys.stderr, flush=True)
@@ -168,7 +177,7 @@ def main():
         elbo = e_ if e_ is not None else elbo
         it0 += args.steps
     if dist is not None:   # MAX over ranks, block by block
-        tt = torch.tensor(blocks, dtype=torch.float64, device=dev)
+        tt = torch.tensor(blocks, dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         blocks = [float(v) for v in tt.tolist()]
     dt = float(np.median(blocks))
@@ -178,7 +187,7 @@ def main():
         elbo = eng.elbo()
     if dist is not None:
         # the path's only exchange: gather the per-fit ELBOs (RCCL over xGMI)
-        mine = torch.tensor([elbo], dtype=torch.float64, device=dev)
+        mine = torch.tensor([elbo], dtype=torch.float64, device=cdev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         elbos = [float(v.item()) for v in allv]
@@ -203,7 +212,7 @@ def main():
                       else f"CAVI iterations/sec ({args.config})",
             "value": world * args.steps / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: ranks share a GPU, gloo)",
             "config": {"workload": f"BASELINE configs[2]: StandardSBM-style synthetic L={L} N={N} M={M} K={K}, "
                                    f"eta={cfg['eta']}, R dense all-ones, one seed-fit per GPU" if args.config == "c3"
                                    else args.config,
@@ -409,7 +418,7 @@ def launch_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not os.environ.get("VMR_BENCH_REHEARSE"):
         print(f"bench.py: --gpus {n} but this node has {have} GPU(s); refusing to report a {n}-GPU number", file=sys.stderr)
         return 2
     s = socket.socket()
