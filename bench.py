@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (roofline then has no live launch time)")
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_layer / small_fits blocks after the timed region")
     ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra blocks")
+    ap.add_argument("--c5-nodes", type=int, default=8000, help="--config c5: nodes per layer (the stated configuration is 8000; smaller only to rehearse)")
     ap.add_argument("--villages", type=int, default=16, help="--config c4: synthetic villages (x 4 layers x --seeds fits)")
     ap.add_argument("--seeds", type=int, default=3, help="--config c4: seeds per (village, layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,9 +117,9 @@ def main():
     if world > 1 and rank == 0:
         print(f"bench.py: RCCL world size {dist.get_world_size()} (backend {dist.get_backend()}), one rank per GPU", file=sys.stderr, flush=True)
     if args.config == "c5":
-        return bench_c5_sharded(args, rank, world, local, dev, dist)
+        return bench_c5_sharded(args, rank, world, local, dev, dist, N=args.c5_nodes, cdev=cdev)
     if args.config == "c4":
-        return bench_c4_batch(args, rank, world, local, dev, dist)
+        return bench_c4_batch(args, rank, world, local, dev, dist, cdev=cdev)
 
     from vimure_amd import CaviEngine
     from vimure_amd.synthetic import standard_sbm
@@ -338,7 +339,7 @@ def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
             "mean_fit_seconds": float(df["seconds"].mean()), "sweeps_per_s_lower_bound": sweeps / dt}
 
 
-def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3):
+def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3, cdev=None):
     """BASELINE configs[4]: ONE fit whose layers live on different GPUs, one layer per rank (vimure_amd.sharded)."""
     import torch
     from vimure_amd.sharded import fit_layer_sharded
@@ -354,7 +355,7 @@ def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev or dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
         its = res["trace"][-1][2] if res["trace"] else n_sweeps
@@ -369,7 +370,7 @@ def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3):
     dist.destroy_process_group()
 
 
-def bench_c4_batch(args, rank, world, local, dev, dist):
+def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
     """BASELINE configs[3]: (village, layer, seed) fits sharded over the ranks, gathered with one all_gather."""
     import torch
     import warnings
@@ -395,7 +396,7 @@ def bench_c4_batch(args, rank, world, local, dev, dist):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev or dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
