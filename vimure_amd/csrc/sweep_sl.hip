@@ -429,7 +429,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // lane needs it.  Rounds past the step's last are empty entries.
         constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
         rounds(RC<GB>{}, [&](const unsigned (&c)[GB]) SL_INL {
-          if (lim1 == 0xffffffffu) { walk1_near(c, RC<GB>{}, U); return; }
+          if (ymax < lim1) { walk1_near(c, RC<GB>{}, U); return; }   // (this step's reports all lie in the LDS levels of F: known per step)
           double f[GB][K];
           bool fr[GB];
 #pragma unroll
