@@ -25,10 +25,10 @@
 #define SL_YM_ROWS (1u << 20)  // (max count + 1) * Mp must not exceed this
 #define SL_PF 8                // steps of up to this many rounds run in straight-line code compiled for their round count
 // rounds of a step that are prefetched one step ahead (registers) = the depth of the ring that streams the further rounds of a
-// longer step: what a wave keeps in flight.  K >= 3 has the register budget (sl_wpe) for 16: a config-5 layer has 19 reports
-// per tie, and with 8 its steps ran at the latency of 8 x 256 B per wave (N = 3000 layer: rho pass 0.87 ms).
+// longer step: what a wave keeps in flight.  8 for every K: with 16 (tried for K >= 3, whose budgets have the registers) a
+// 19-report step of a config-5 layer issues 32 loads for 19 reports, and the over-fetch costs more than the depth hides.
 #ifndef SL_PFW
-#define SL_PFW 16
+#define SL_PFW 8    // (a multiple of 8; 16: config-5 sweep 3.63 instead of 3.53 ms)
 #endif
 constexpr int sl_pf(int K) { return K <= 2 ? SL_PF : SL_PFW; }
 #define SL_SLACK (64 * 64)     // entry slots past the last one that prefetches may read (never use)
