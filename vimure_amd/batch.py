@@ -95,7 +95,16 @@ class _LockstepFit:
         """Draws the next realisation's initial state on the host (into the engine's staging buffer); False when there is none
         left.  May run while the previous realisation's loop is on the GPU: it touches no device state."""
         t0 = time.perf_counter()
-        self._item = next(self.states, None)
+        self._item = item = next(self.states, None)
+        if item is not None and item[0] > 0 and self.eng.can_upload_ahead():
+            # the upload too leaves the critical path (a device slot of its own, r % 2: the previous use of that slot was consumed
+            # by set_state two realisations ago; realisation 0 has nothing to hide behind)
+            si = self.m._staging_index(self.eng, item[0])
+            pr = item[2]["pr_rho"]
+            if isinstance(pr, np.ndarray) and np.shares_memory(pr, self.eng.staging(si)):
+                dev = self.eng.upload_ahead(si, item[0] % 2)
+                if dev is not None:
+                    item[2]["pr_rho"] = dev
         self.m.draw_seconds += time.perf_counter() - t0
         return self._item is not None
 
