@@ -39,6 +39,11 @@ struct SlArgs {
   const uint8_t* cls;    // [L][T] mask-row class by position: 0 empty, 1 all ones, 2 partial (null: every row is all ones)
   const unsigned* Qt;    // [L][T] by position: sum_m R[t,m] X[mirror(t),m]
   const uint64_t* Rb; const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // mask rows, by TIE
+  // Mask lists of at most two reporters (the self-reporter mask of survey data: R[l,i,j,m] = 1 iff m is i or j), BY POSITION:
+  // m0 | m1 << 16, 0xffff = none.  Prefetched with the tie's other values one step ahead, so a partial row costs two LDS reads
+  // of E[theta] instead of three dependent global loads (tie -> list range -> reporters -> E[theta]) inside the step -- which was
+  // what a step of a Karnataka-sized layer took its time for.  null: the lists by tie (rq / Rm).
+  const unsigned* rm2;
   double* rho; const double* logpr;   // [L][T][K] by position
   const double* par; double* slotR; const double* lutg; double* Hg; double* slotF; double* slotA;
   int Gl;        // workgroups per layer
@@ -84,7 +89,7 @@ constexpr int sl_wpe(int K, bool elbo, bool allfull, bool update = true) {
 static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
   return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * lb : 0) + (size_t)g.Mp * 8 * (update ? 2 : 1) +
-         (size_t)g.W * 8 + 128 + (g.ml ? lb : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
+         (size_t)g.W * 8 + 128 + (g.ml ? lb + (size_t)g.Mp * 8 : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
 }
 
 // mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2)

@@ -81,6 +81,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
   double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;
   double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
+  double* EthL = reinterpret_cast<double*>(smem + off); off += a.rq ? (size_t)Mp * 8 : 0;   // E[theta] for the mask lists
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = (int)bx / a.Gl, gb = (int)bx - l * a.Gl;
 #ifdef SL_DEBUG
@@ -96,6 +97,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   }
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
   if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
+  if (a.rq) for (int m = tid; m < Mp; m += nthr) EthL[m] = m < g.M ? a.par[o.E_th + (size_t)l * Mp + m] : 0.0;
   if (UPDATE || ELBO) sp_math_tables(xt, lt, tid, nthr);
   const double* lut = a.lutg + (size_t)l * g.W * 256;
   for (int w = tid; w < g.W; w += nthr) {
@@ -121,7 +123,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   const unsigned* rsl = a.rs + (size_t)l * (NS + 1);
   const unsigned* syl = a.sy + (size_t)l * NS;
   const unsigned* El = a.E + a.ebase[l];
-  const unsigned* pl = a.perm + (size_t)l * NS * 64;
+  const unsigned* pl = (a.rm2 ? a.rm2 : a.perm) + (size_t)l * NS * 64;   // (the `tie` slot of a step: the tie, or its packed list)
   const uint8_t* cl = ALLFULL ? nullptr : a.cls + (size_t)l * T;
   const unsigned* Ql = a.Qt ? a.Qt + (size_t)l * T : nullptr;
   const uint64_t* Rl = a.Rb ? a.Rb + (size_t)l * T * g.W : nullptr;
@@ -130,7 +132,6 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   const double* lpl = a.logpr + (size_t)l * T * K;
   const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
   const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
-  const double* Eth = a.par + o.E_th + (size_t)l * Mp;
   // a step is "far" when one of its reports lies in a level beyond the LDS copies this launch holds: it takes the general body,
   // which decides per group of reports (lim1 / lim2: first level beyond the copies of F / H, none when every level is held)
   const unsigned lim_y = UPDATE ? (a.do_hist ? (unsigned)min(a.yt, a.hc) : (unsigned)a.yt) : (a.do_hist ? (unsigned)a.hc : 0xffffffffu);
@@ -223,6 +224,27 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // ---- pieces of a step -------------------------------------------------------------------------------------------
   // A[m][k] += rho_k of this lane's tie over its listed reporters (partial mask rows; model.py:704-718, 742-749)
   auto add_lists = [&](unsigned t, bool on, const double (&rr)[K]) SL_INL {
+    if (a.rm2) {   // t = m0 | m1 << 16 (SlArgs::rm2)
+#pragma unroll
+      for (int h_ = 0; h_ < 2; ++h_) {
+        const unsigned m = h_ ? (t >> 16) : (t & 0xffffu);
+        const bool v = on && m != 0xffffu;
+        const unsigned long long vm = __ballot(v);
+        if (vm == 0ull) continue;
+        const int m0 = __builtin_amdgcn_readlane((int)m, __builtin_ctzll(vm));
+        if (__all(!v || (int)m == m0)) {   // one reporter for the whole wave (ties (i, j..j+63)): one add instead of 64 on one address
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const double sm_ = wave_sum(v ? rr[k] : 0.0);
+            if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
+          }
+        } else if (v) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
+        }
+      }
+      return;
+    }
     unsigned q0 = 0, q1 = 0;
     if (on) { q0 = rql[t]; q1 = rql[t + 1]; }
     for (unsigned i = 0;; ++i) {
@@ -248,9 +270,12 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     if (ALLFULL) return Tfull;
     double Tt = 0.0;
     if (cls == 1u) Tt = Tfull;
-    else if (cls == 2u && rql) {
+    else if (cls == 2u && a.rm2) {   // (tie = m0 | m1 << 16)
+      const unsigned m0 = tie & 0xffffu, m1 = tie >> 16;
+      Tt = (m0 != 0xffffu ? EthL[m0] : 0.0) + (m1 != 0xffffu ? EthL[m1] : 0.0);
+    } else if (cls == 2u && rql) {
       const unsigned q0 = rql[tie], q1 = rql[tie + 1];
-      for (unsigned q = q0; q < q1; ++q) Tt += Eth[Rml[q]];
+      for (unsigned q = q0; q < q1; ++q) Tt += EthL[Rml[q]];
     } else if (cls == 2u) {
       const uint64_t* rwt = Rl + (size_t)tie * g.W;
       for (int w = 0; w < g.W; ++w) {

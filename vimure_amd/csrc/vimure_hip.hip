@@ -1748,7 +1748,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   return s;
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
-  return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par, h->slotR,
+  return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
                 h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0};
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
@@ -2165,6 +2165,7 @@ static int mask_lists_from_words(vmr_ctx* h) {
   unsigned maxrow = 0;
   CK(hipMemcpy(rl_.data(), tot_dev, (size_t)L * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(&maxrow, max_dev, 4, hipMemcpyDeviceToHost));
+  h->rm_maxrow = maxrow;
   CK(hipFree(tot_dev));
   CK(hipFree(max_dev));
   bool ok32 = true;
@@ -2209,6 +2210,24 @@ __global__ __launch_bounds__(256) void k_level_hist(const unsigned* __restrict__
   for (int i = threadIdx.x; i < 65; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
+// the mask lists of at most two reporters, packed by sorted position (SlArgs::rm2)
+__global__ __launch_bounds__(256) void k_rm2(const unsigned* __restrict__ perm, const unsigned* __restrict__ rq, const unsigned short* __restrict__ Rm,
+                                             const unsigned long long* __restrict__ rbase, unsigned* __restrict__ out, size_t T, size_t NS, int L) {
+  const size_t n = (size_t)L * NS * 64;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const size_t l = q / (NS * 64);
+    const unsigned tie = perm[q];
+    unsigned w = 0xffffffffu;
+    if (tie != 0xffffffffu) {
+      const unsigned q0 = rq[l * (T + 1) + tie], q1 = rq[l * (T + 1) + tie + 1];
+      const unsigned short* r = Rm + rbase[l];
+      const unsigned m0 = q1 > q0 ? r[q0] : 0xffffu, m1 = q1 > q0 + 1 ? r[q0 + 1] : 0xffffu;
+      w = m0 | (m1 << 16);
+    }
+    out[q] = w;
+  }
+}
+
 static int sl_finish(vmr_ctx* h) {
   const Geo& g = h->g;
   const size_t rows = (size_t)g.L * g.N * g.N;
@@ -2233,6 +2252,12 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
   const int L = g.L, K = g.K;
   g.ml = (h->sparse && h->rq) ? 1 : 0;
+  if (g.ml && h->rm_maxrow <= 2 && !getenv("VMR_NO_RM2")) {   // (the self-reporter mask of survey data: lists of two)
+    const size_t T_ = (size_t)g.N * g.N, NS_ = (T_ + 63) / 64, n_ = (size_t)L * NS_ * 64;
+    CK(hipMalloc(&h->rm2, n_ * 4));
+    hipLaunchKernelGGL(k_rm2, dim3((unsigned)std::min<size_t>(4096, (n_ + 255) / 256)), dim3(256), 0, h->stream, h->perm, h->rq, h->Rm, h->rbase, h->rm2, T_, NS_, L);
+    CK(hipGetLastError());
+  }
   // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
   g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
   g.yt = 0;
@@ -2673,6 +2698,7 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   unsigned maxrow = 0;
   CKC(hipMemcpy(&bad, bad_dev, 4, hipMemcpyDeviceToHost));
   CKC(hipMemcpy(&maxrow, maxrow_dev, 4, hipMemcpyDeviceToHost));
+  h->rm_maxrow = maxrow;
   if (bad) {
     cleanup();
     return fail(nullptr, VMR_EINVAL, (bad & 1) ? "a subscript lies outside (L, N, N, M)"
@@ -2764,7 +2790,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

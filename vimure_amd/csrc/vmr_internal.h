@@ -106,6 +106,8 @@ struct vmr_ctx {
   unsigned short* Rm = nullptr;
   unsigned long long* rbase = nullptr; // device [L]
   unsigned long long n_rm = 0;         // listed reporters in all
+  unsigned rm_maxrow = 0;              // longest list
+  unsigned* rm2 = nullptr;             // [L][NS * 64] by sorted position, when no list is longer than 2 (SlArgs::rm2)
   unsigned long long* sumx = nullptr;
   // state
   double *rho = nullptr, *logpr = nullptr;
