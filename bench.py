@@ -370,6 +370,29 @@ def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3, c
     dist.destroy_process_group()
 
 
+def village_coo(N, seed, dev, L=4):
+    """A Karnataka-shaped village as the reader delivers it -- coordinate containers of X and of the self-reporter mask R (R[l,i,j,m]
+    = 1 iff m is i or j, `_io.py:230-242`) -- drawn on the device (the host generator needs minutes for N = 800) and masked there."""
+    import torch
+    from vimure_amd.synthetic import standard_sbm
+    from vimure_amd.tensor import SparseTensor
+    net = standard_sbm(N=N, M=N, L=L, K=2, avg_degree=3.0, eta=0.3, seed=seed, device=dev)
+    idx = torch.nonzero(net.X)   # row-major order, as np.nonzero
+    idx = idx[(idx[:, 3] == idx[:, 1]) | (idx[:, 3] == idx[:, 2])]
+    vals = net.X[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]].cpu().numpy().astype(np.int64)
+    X = SparseTensor(tuple(idx[:, d].cpu().numpy() for d in range(4)), vals, shape=(L, N, N, N))
+    del net, idx
+    torch.cuda.empty_cache()
+    ll, ii, jj = (a.ravel() for a in np.meshgrid(np.arange(L), np.arange(N), np.arange(N), indexing="ij"))
+    lo, hi = np.minimum(ii, jj), np.maximum(ii, jj)
+    keep = np.ones(2 * len(ll), bool)
+    keep[1::2] = lo != hi   # (i == j: one reporter)
+    rep2 = lambda a: np.repeat(a, 2)[keep]
+    mm = np.stack([lo, hi], axis=1).ravel()[keep]
+    R = SparseTensor((rep2(ll), rep2(ii), rep2(jj), mm), np.ones(len(mm), np.int64), shape=(L, N, N, N))
+    return X, R
+
+
 def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
     """BASELINE configs[3]: (village, layer, seed) fits sharded over the ranks, gathered with one all_gather."""
     import torch
@@ -382,8 +405,7 @@ def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
     sizes = g.randint(200, 801, size=args.villages)   # the measured village sizes of the reference's data: N ~ 200-800
     data = {}
     for v, N in enumerate(sizes):
-        net = standard_sbm(N=int(N), M=int(N), L=4, K=2, avg_degree=3.0, eta=0.3, seed=v, flag_self_reporter=True)
-        data[f"vil{v:02d}"] = (SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R))
+        data[f"vil{v:02d}"] = village_coo(int(N), v, dev)
     fit_datasets({"w": data["vil00"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=local)   # warm-up
     if dist is not None:
         dist.barrier()
