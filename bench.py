@@ -325,10 +325,7 @@ def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
     from vimure_amd.synthetic import standard_sbm
     from vimure_amd.tensor import SparseTensor
     warnings.simplefilter("ignore")
-    data = {}
-    for v, N in enumerate(sizes):
-        net = standard_sbm(N=N, M=N, L=4, K=2, avg_degree=3.0, eta=0.3, seed=v, flag_self_reporter=True)
-        data[f"vil{v}"] = (SparseTensor.fromarray(net.X), SparseTensor.fromarray(net.R))
+    data = {f"vil{v}": village_coo(N, v, f"cuda:{device}") for v, N in enumerate(sizes)}
     fit_datasets({"w": data["vil0"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=device)   # warm-up
     t0 = time.perf_counter()
     df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=8, device=device)
