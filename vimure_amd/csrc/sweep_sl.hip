@@ -861,22 +861,25 @@ int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlAr
   }
 }
 
-// the rho update (mode 0) or rho update + ELBO data terms (mode 1) of `nblocks` workgroups' worth of units in one launch
-template <bool ELBO, bool ALLFULL>
+// the rho update (mode 0), rho update + ELBO data terms (mode 1) or the statistics of the current rho (mode 3: a realisation's
+// first sweep) of `nblocks` workgroups' worth of units in one launch
+template <bool UPDATE, bool ELBO, bool ALLFULL>
 static int sl_launch_batch_one(vmr_ctx* h, hipStream_t st, const SlUnit* units, const int* blk_unit, int nblocks, int tpb, size_t smem) {
   constexpr int K = VMR_K;
   static size_t attr = 48 * 1024;   // (largest dynamic LDS size this kernel has been given leave for)
   if (smem > attr) {
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, true, ELBO, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = smem;
   }
-  hipLaunchKernelGGL((k_sweep_sl_b<K, true, ELBO, ALLFULL>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
+  hipLaunchKernelGGL((k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
   return VMR_OK;
 }
 int SL_CAT(vmr_sl_launch_batch_k, VMR_K)(vmr_ctx* h, hipStream_t st, int mode, int allfull, const SlUnit* units, const int* blk_unit, int nblocks,
                                           int tpb, size_t smem) {
-  if (allfull) return mode ? sl_launch_batch_one<true, true>(h, st, units, blk_unit, nblocks, tpb, smem)
-                           : sl_launch_batch_one<false, true>(h, st, units, blk_unit, nblocks, tpb, smem);
-  return mode ? sl_launch_batch_one<true, false>(h, st, units, blk_unit, nblocks, tpb, smem)
-              : sl_launch_batch_one<false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
+  if (mode == 3) return allfull ? sl_launch_batch_one<false, false, true>(h, st, units, blk_unit, nblocks, tpb, smem)
+                                : sl_launch_batch_one<false, false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
+  if (allfull) return mode ? sl_launch_batch_one<true, true, true>(h, st, units, blk_unit, nblocks, tpb, smem)
+                           : sl_launch_batch_one<true, false, true>(h, st, units, blk_unit, nblocks, tpb, smem);
+  return mode ? sl_launch_batch_one<true, true, false>(h, st, units, blk_unit, nblocks, tpb, smem)
+              : sl_launch_batch_one<true, false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
 }

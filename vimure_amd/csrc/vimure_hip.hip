@@ -3032,14 +3032,14 @@ static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
 }
 namespace {
 struct BatchTables {   // device copies of the unit tables of one lockstep loop
-  SlUnit* su[2] = {nullptr, nullptr};   // mode 0 / 1
-  int* smap[2] = {nullptr, nullptr};
+  SlUnit* su[3] = {nullptr, nullptr, nullptr};   // mode 0 / 1; [2]: the statistics pass of a realisation's first sweep
+  int* smap[3] = {nullptr, nullptr, nullptr};
   FinUnit* fu = nullptr;
   int *gmap = nullptr, *rmap = nullptr;
   double* be = nullptr;                 // [n][8]: every unit's elbo_dev
-  int nb[2] = {0, 0}, ngb = 0, nrb = 0, tpb[2] = {0, 0};
-  size_t smem[2] = {0, 0}, fsm = 0;
-  ~BatchTables() { for (void* p : {(void*)su[0], (void*)su[1], (void*)smap[0], (void*)smap[1], (void*)fu, (void*)gmap, (void*)rmap, (void*)be}) if (p) (void)hipFree(p); }
+  int nb[3] = {0, 0, 0}, ngb = 0, nrb = 0, tpb[3] = {0, 0, 0};
+  size_t smem[3] = {0, 0, 0}, fsm = 0;
+  ~BatchTables() { for (void* p : {(void*)su[0], (void*)su[1], (void*)su[2], (void*)smap[0], (void*)smap[1], (void*)smap[2], (void*)fu, (void*)gmap, (void*)rmap, (void*)be}) if (p) (void)hipFree(p); }
 };
 }  // namespace
 // (re)builds the tables for the units listed in `act`
@@ -3050,7 +3050,7 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
   for (int u : act) steps += (((long long)hs[u]->g.N * hs[u]->g.N + 63) / 64) * hs[u]->g.L;
   std::vector<FinUnit> fu(act.size());
   std::vector<int> gmap, rmap;
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < 3; ++m) {
     const int tpb = sl_tpb_max_b(K, m == 1, allfull), nw = tpb / 64;
     // steps per wave: about one workgroup per CU in all (the tables in LDS allow few more, and a second round of workgroups
     // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each
@@ -3061,10 +3061,10 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
     for (size_t i = 0; i < act.size(); ++i) {
       vmr_ctx* h = hs[act[i]];
       const Geo& g = h->g;
-      const SlShape sh = sl_shape(h, true, m == 1, true);
+      const SlShape sh = sl_shape(h, m != 2, m == 1, true);
       SlArgs a = sl_args(h, sh, 1, g.ml ? 1 : 0);
       a.elbo_dev = bt.be + (size_t)act[i] * 8;
-      if (g.mut) { a.nu_acc = h->nu_acc; a.commit_nu = 1; }
+      if (g.mut && m != 2) { a.nu_acc = h->nu_acc; a.commit_nu = 1; }   // (the statistics of the initial rho leave nu alone)
       const long long NS = ((long long)g.N * g.N + 63) / 64;
       a.Gl = (int)std::max<long long>(1, std::min<long long>(4096, (NS + nw * per - 1) / (nw * per)));
       su[i].a = a; su[i].g = g; su[i].blk0 = (int)map.size(); su[i].nblk = g.L * a.Gl;
@@ -3136,19 +3136,24 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
   if (act.size() < 2 || max_iter < 2) { for (int u : act) solo(u); return finish(); }
   vmr_ctx* h0 = hs[act[0]];
   HIPCHK(h0, hipSetDevice(h0->device));
-  // iteration 1 (the ELBO is evaluated there, model.py:1036) on every handle's own stream: it builds the statistics of the
-  // initial rho -- launches the steady sweeps do not have
-  for (int u : act) { rc_out[u] = sweep(hs[u], 1); }
-  for (size_t i = 0; i < act.size();) {
-    const int u = act[i];
-    if (!rc_out[u]) rc_out[u] = read_elbo(hs[u], &ls[u].elbo);
-    if (rc_out[u]) { (void)hipStreamSynchronize(hs[u]->stream); act.erase(act.begin() + i); continue; }
-    ls[u].coincide = (fabs(ls[u].elbo - (-1e10)) < tol) ? 1 : 0;
-    if (ls[u].coincide > decision) ls[u].reached = 1;
-    ls[u].it = 2;
-    if (ls[u].reached) { act.erase(act.begin() + i); continue; }
-    if (!batch_steady(hs[u])) { solo(u); act.erase(act.begin() + i); continue; }
-    ++i;
+  // Iteration 1 (the ELBO is evaluated there, model.py:1036) also builds the statistics of the initial rho -- launches the
+  // steady sweeps do not have.  Handles that come straight from vmr_set_state take it inside the tables (below); if some do
+  // not, every handle runs it on its own stream.
+  bool fresh = true;
+  for (int u : act) fresh = fresh && !hs[u]->h_valid && !hs[u]->prof;
+  if (!fresh) {
+    for (int u : act) { rc_out[u] = sweep(hs[u], 1); }
+    for (size_t i = 0; i < act.size();) {
+      const int u = act[i];
+      if (!rc_out[u]) rc_out[u] = read_elbo(hs[u], &ls[u].elbo);
+      if (rc_out[u]) { (void)hipStreamSynchronize(hs[u]->stream); act.erase(act.begin() + i); continue; }
+      ls[u].coincide = (fabs(ls[u].elbo - (-1e10)) < tol) ? 1 : 0;
+      if (ls[u].coincide > decision) ls[u].reached = 1;
+      ls[u].it = 2;
+      if (ls[u].reached) { act.erase(act.begin() + i); continue; }
+      if (!batch_steady(hs[u])) { solo(u); act.erase(act.begin() + i); continue; }
+      ++i;
+    }
   }
   if (act.size() < 2) { for (int u : act) solo(u); return finish(); }
   h0 = hs[act[0]];
@@ -3162,7 +3167,7 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
       const Geo& g = hs[u]->g;
       blocks += (size_t)g.L * 4096; gb += (size_t)g.L * FG_G; rb += (size_t)g.L * FR_G;
     }
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 3; ++m) {
       HIPCHK(h0, hipMalloc(&bt.su[m], act.size() * sizeof(SlUnit)));
       HIPCHK(h0, hipMalloc(&bt.smap[m], blocks * sizeof(int)));
     }
@@ -3183,13 +3188,28 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
     HIPCHK(h0, hipGetLastError());
     return VMR_OK;
   };
-  int it = 2;   // every active unit stands at the same iteration
+  int it = fresh ? 1 : 2;   // every active unit stands at the same iteration
   while (!act.empty() && it <= max_iter) {
-    const int nxt = (it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
+    const int nxt = (it == 1 || it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
     for (; it < nxt; ++it) if ((rc = launch_sweeps(0))) break;
     if (rc) break;
     HIPCHK(h0, hipStreamSynchronize(st));
     const auto t0 = std::chrono::steady_clock::now();
+    if (it == 1) {
+      // the first sweep of the realisations: H, the all-ones sums and the mask sums of the initial rho (launch_hist, for all units)
+      for (int u : act) {
+        vmr_ctx* h = hs[u];
+        const Geo& g = h->g;
+        HIPCHK(h0, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, st));
+        HIPCHK(h0, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, st));
+        if (g.ml) HIPCHK(h0, hipMemsetAsync(h->slotA, 0, (size_t)g.L * NSLOT * g.W * 64 * g.K * 8, st));
+      }
+      if ((rc = pass(h0, st, 3, allfull, bt.su[2], bt.smap[2], bt.nb[2], bt.tpb[2], bt.smem[2]))) break;
+      for (int u : act) {   // (where a sweep leaves a handle: statistics of the current rho in place, nothing folded or zeroed)
+        vmr_ctx* h = hs[u];
+        h->h_valid = true; h->h_zero = false; h->h_reduced = false; h->f_valid = h->g.fuse_full != 0; h->a_valid = h->g.ml != 0; h->a_zero = false;
+      }
+    }
     if ((rc = launch_sweeps(1))) break;
     HIPCHK(h0, hipMemcpyAsync(be_host.data(), bt.be, (size_t)n * 8 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h0, hipStreamSynchronize(st));
