@@ -315,10 +315,10 @@ def c5_layer_block(device, N=8000, M=1000, K=3, sweeps=10):
             "elbo_after_sweeps": e, "setup_seconds": t_setup}
 
 
-def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600), n_seeds=3):
+def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600, 250, 350, 500, 550, 300, 400, 220, 280), n_seeds=3):
     """BASELINE configs[3] shape (tools/bench_batch.py): Karnataka-like villages (self-reporter mask, M-dim = N, 4 layers fitted
     separately, K=2, 5 realisations x <= 101 iterations per fit; karnataka.py:170-191) through vimure_amd.batch from ONE
-    process: the 16 (village, layer) units advance in lockstep, one launch per kernel and sweep for all of them
+    process: the (village, layer) units -- 48 here; the reference's experiment has 300 -- advance in lockstep, one launch per kernel and sweep for all of them
     (vmr_fit_loop_batch), the seeds one after the other.  Outside the timed region of `value`."""
     import warnings
     from vimure_amd.batch import fit_datasets
