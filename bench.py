@@ -48,6 +48,10 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# host threads of the small-fit drivers (RandomState draws of the initial states, uploads, read-backs): env VMR_BENCH_WORKERS
+HOST_WORKERS = int(os.environ.get("VMR_BENCH_WORKERS", "8"))
+
+
 def draw_state(cfg, seed, sum_x, coverage):
     """RandomState-exact initial state through the host class (reference model.py:458-605)."""
     from vimure_amd.model import VimureModel
@@ -328,11 +332,11 @@ def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600, 250, 350, 500,
     data = {f"vil{v}": village_coo(N, v, f"cuda:{device}") for v, N in enumerate(sizes)}
     fit_datasets({"w": data["vil0"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=device)   # warm-up
     t0 = time.perf_counter()
-    df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=8, device=device)
+    df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=HOST_WORKERS, device=device)
     dt = time.perf_counter() - t0
     sweeps = float(df["iters"].sum())   # (iterations of the best realisation only: a lower bound on the sweeps run)
     return {"workload": f"{len(sizes)} villages N={list(sizes)} x 4 layers x {n_seeds} seeds, 5 realisations x <= 101 iterations each",
-            "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": 8, "lockstep_units": 4 * len(sizes),
+            "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": HOST_WORKERS, "lockstep_units": 4 * len(sizes),
             "mean_fit_seconds": float(df["seconds"].mean()), "sweeps_per_s_lower_bound": sweeps / dt}
 
 
@@ -408,7 +412,7 @@ def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    df = fit_datasets(data, K=2, seeds=range(args.seeds), num_realisations=5, max_iter=101, workers=8, device=local,
+    df = fit_datasets(data, K=2, seeds=range(args.seeds), num_realisations=5, max_iter=101, workers=HOST_WORKERS, device=local,
                       dist=dist if world > 1 else None)
     torch.cuda.synchronize()
     if dist is not None:
