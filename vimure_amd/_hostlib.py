@@ -41,11 +41,14 @@ def _load_locked():
 
 
 _pool = None
+max_threads = None   # a cap on the threads of ONE draw (the lockstep batch driver draws many states side by side: 1 each)
 
 
 def _threads():
     global _pool
     n = max(1, min(32, os.cpu_count() or 1))
+    if max_threads is not None:
+        n = max(1, min(n, int(max_threads)))
     if _pool is None and n > 1:
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="vmr-draw")

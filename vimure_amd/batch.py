@@ -116,7 +116,10 @@ class _LockstepFit:
     def end(self, rows, elbo):
         m = self.m
         self.trace.extend((self.r, self.seed_r, it_, e_, rt_, rc_) for it_, e_, rt_, rc_ in rows)
-        m._pull_params(self.eng)
+        # the small posteriors cross PCIe only when somebody will look at them: the best realisation so far (`*_f`) and the last
+        # one (what `gamma_shp` ... hold after `fit`, as in the reference)
+        if self.maxL < elbo or self.r == m.num_realisations - 1:
+            m._pull_params(self.eng)
         if self.maxL < elbo:
             self.maxL, self.best = elbo, m._params_copy()
             if m.num_realisations > 1 and self.need_rho:
@@ -153,6 +156,8 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
         clock[key] += time.perf_counter() - t
         return r
     order = sorted(range(len(units)), key=lambda i: -float(units[i][1].shape[1]))   # similar sizes side by side
+    from . import _hostlib
+    cap_before, _hostlib.max_threads = _hostlib.max_threads, 1   # many draws side by side: one host thread each
     with ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="vmr-draw") as ex:
         for g0 in range(0, len(order), max(1, width)):
             group = [units[i] for i in order[g0:g0 + max(1, width)]]
@@ -198,6 +203,7 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
             finally:
                 for e in engs:
                     e.close()
+    _hostlib.max_threads = cap_before
     if os.environ.get("VMR_BATCH_TIMING"):
         print("fit_units_lockstep seconds:", {k: round(v, 3) for k, v in clock.items()}, flush=True)
     return out

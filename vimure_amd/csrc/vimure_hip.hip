@@ -3326,29 +3326,35 @@ int vmr_sub_step(vmr_handle h, int which) {
   }
 }
 
-static int download_lm(vmr_ctx* h, size_t off, double* dst) {
-  const Geo& g = h->g;
-  std::vector<double> buf((size_t)g.L * g.Mp);
-  HIPCHK(h, hipMemcpyAsync(buf.data(), h->par + off, buf.size() * 8, hipMemcpyDeviceToHost, h->stream));
+// the whole parameter block in ONE copy (tens of KB): the getters of the small posteriors are called once per realisation of every
+// small fit, from several host threads -- six small copies with a synchronisation each cost them a millisecond per call
+static int fetch_par(vmr_ctx* h, std::vector<double>& buf) {
+  buf.resize(h->par_doubles);
+  HIPCHK(h, hipMemcpyAsync(buf.data(), h->par, h->par_doubles * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int l = 0; l < g.L; ++l) memcpy(dst + (size_t)l * g.M, &buf[(size_t)l * g.Mp], (size_t)g.M * 8);
   return VMR_OK;
+}
+static void rows_lm(const Geo& g, const std::vector<double>& buf, size_t off, double* dst) {
+  for (int l = 0; l < g.L; ++l) memcpy(dst + (size_t)l * g.M, &buf[off + (size_t)l * g.Mp], (size_t)g.M * 8);
 }
 
 int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* phi_shp, double* phi_rte,
                   double* nu_shp, double* nu_rte, double* rho) {
   if (!h) return VMR_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   const Geo& g = h->g;
   ParOff o = par_off(g.L, g.Mp, g.K);
   int rc;
-  if (gamma_shp && (rc = download_lm(h, o.g_shp, gamma_shp))) return rc;
-  if (gamma_rte && (rc = download_lm(h, o.g_rte, gamma_rte))) return rc;
-  if (phi_shp && (rc = d2h(h, phi_shp, h->par + o.p_shp, (size_t)g.L * g.K * 8))) return rc;
-  if (phi_rte && (rc = d2h(h, phi_rte, h->par + o.p_rte, (size_t)g.L * g.K * 8))) return rc;
-  if (nu_shp && (rc = d2h(h, nu_shp, h->par + o.sc + SC_NU_SHP, 8))) return rc;
-  if (nu_rte && (rc = d2h(h, nu_rte, h->par + o.sc + SC_NU_RTE, 8))) return rc;
+  if (gamma_shp || gamma_rte || phi_shp || phi_rte || nu_shp || nu_rte) {
+    std::vector<double> buf;
+    if ((rc = fetch_par(h, buf))) return rc;
+    if (gamma_shp) rows_lm(g, buf, o.g_shp, gamma_shp);
+    if (gamma_rte) rows_lm(g, buf, o.g_rte, gamma_rte);
+    if (phi_shp) memcpy(phi_shp, &buf[o.p_shp], (size_t)g.L * g.K * 8);
+    if (phi_rte) memcpy(phi_rte, &buf[o.p_rte], (size_t)g.L * g.K * 8);
+    if (nu_shp) *nu_shp = buf[o.sc + SC_NU_SHP];
+    if (nu_rte) *nu_rte = buf[o.sc + SC_NU_RTE];
+  }
   if (rho) {
     const size_t nr = (size_t)g.L * g.N * g.N * g.K;
     const double* src = h->rho;
@@ -3366,15 +3372,15 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
 int vmr_get_geometric(vmr_handle h, double* g_theta, double* g_lambda, double* g_nu, double* g_nu_cache) {
   if (!h) return VMR_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   const Geo& g = h->g;
   ParOff o = par_off(g.L, g.Mp, g.K);
   int rc;
-  if (g_theta && (rc = download_lm(h, o.G_th, g_theta))) return rc;
-  if (g_lambda && (rc = d2h(h, g_lambda, h->par + o.G_la, (size_t)g.L * g.K * 8))) return rc;
-  if (g_nu && (rc = d2h(h, g_nu, h->par + o.sc + SC_G_NU, 8))) return rc;
-  if (g_nu_cache && (rc = d2h(h, g_nu_cache, h->par + o.sc + SC_G_NU_STALE, 8))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<double> buf;
+  if ((rc = fetch_par(h, buf))) return rc;
+  if (g_theta) rows_lm(g, buf, o.G_th, g_theta);
+  if (g_lambda) memcpy(g_lambda, &buf[o.G_la], (size_t)g.L * g.K * 8);
+  if (g_nu) *g_nu = buf[o.sc + SC_G_NU];
+  if (g_nu_cache) *g_nu_cache = buf[o.sc + SC_G_NU_STALE];
   return VMR_OK;
 }
 
