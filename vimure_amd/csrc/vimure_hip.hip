@@ -1256,15 +1256,15 @@ template <bool det /*Geo::det: sums whose order would vary are integer or in slo
 __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const double* __restrict__ Cg, double* slotA, double* slotF,
                                                double* lutg, double* Fg, double* fin /*[L][2 KMAX + 2]*/, double* nu_acc,
                                                int nh /*copies of H to fold: NH, or 1 when folded already*/, int do_phi, int consume, const Geo& g,
-                                               const int bx) {
+                                               const int bx, const int fg = FG_G /*workgroups per layer of this launch (<= FG_G)*/) {
   extern __shared__ double dyn[];   // s1[mper]: sum_{y,k} w1 H per reporter; gthn[mper]: the new G_theta
   __shared__ double red[16];
   __shared__ double ela_old[KMAX], gla_old[KMAX], fk[KMAX];
   __shared__ double lla_n[KMAX], gla_n[KMAX];   // the new E[log lambda], G_lambda (for the factor table F)
   __shared__ int last;
   const ParOff o = par_off(g.L, g.Mp, g.K);
-  const int l = bx / FG_G, gq = bx - l * FG_G, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
-  const int mper = (g.M + FG_G - 1) / FG_G, m0 = gq * mper, m1 = min(g.M, m0 + mper), nm = max(0, m1 - m0);
+  const int l = bx / fg, gq = bx - l * fg, K = g.K, Wp = g.W * 64, tid = threadIdx.x;
+  const int mper = (g.M + fg - 1) / fg, m0 = gq * mper, m1 = min(g.M, m0 + mper), nm = max(0, m1 - m0);
   double* s1 = dyn;
   double* gthn = dyn + mper;
   double* finl = fin + (size_t)l * (2 * KMAX + 2);
@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double t = atomicAdd(&finl[2 * KMAX], 1.0);
-    last = (t == (double)(FG_G - 1));
+    last = (t == (double)(fg - 1));
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1492,9 +1492,10 @@ struct FinUnit {
   double *par, *Hg; const double* Cg; double *slotA, *slotF, *lutg, *fin_g, *nu_acc, *slotR, *elbo;   // (elbo: 8 doubles, as vmr_ctx::elbo_dev)
   Geo g; int fg_blk0, fr_blk0, fr_nblk;
 };
-__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit) {
+// (fg workgroups per layer: 16 of them -- the latency of one handle's finalize -- times many units would queue up on the CUs)
+__global__ __launch_bounds__(FIN_TPB) void k_fin_gamma_b(const FinUnit* __restrict__ units, const int* __restrict__ blk_unit, int fg) {
   const FinUnit& u = units[blk_unit[blockIdx.x]];
-  fin_gamma_body<false>(u.par, u.Hg, u.Cg, u.slotA, u.slotF, u.lutg, nullptr, u.fin_g, u.nu_acc, NH, 1, 1, u.g, (int)blockIdx.x - u.fg_blk0);
+  fin_gamma_body<false>(u.par, u.Hg, u.Cg, u.slotA, u.slotF, u.lutg, nullptr, u.fin_g, u.nu_acc, NH, 1, 1, u.g, (int)blockIdx.x - u.fg_blk0, fg);
 }
 
 // phi commit, mutuality on: phi_shp from H with the NEW E[log theta] (model.py:731-733, 861-887; the cache
@@ -3037,7 +3038,7 @@ struct BatchTables {   // device copies of the unit tables of one lockstep loop
   FinUnit* fu = nullptr;
   int *gmap = nullptr, *rmap = nullptr;
   double* be = nullptr;                 // [n][8]: every unit's elbo_dev
-  int nb[3] = {0, 0, 0}, ngb = 0, nrb = 0, tpb[3] = {0, 0, 0};
+  int nb[3] = {0, 0, 0}, ngb = 0, nrb = 0, tpb[3] = {0, 0, 0}, fg = FG_G;
   size_t smem[3] = {0, 0, 0}, fsm = 0;
   ~BatchTables() { for (void* p : {(void*)su[0], (void*)su[1], (void*)su[2], (void*)smap[0], (void*)smap[1], (void*)smap[2], (void*)fu, (void*)gmap, (void*)rmap, (void*)be}) if (p) (void)hipFree(p); }
 };
@@ -3077,14 +3078,19 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
     bt.nb[m] = (int)map.size(); bt.tpb[m] = tpb; bt.smem[m] = smem;
   }
   bt.fsm = 0;
+  {   // workgroups per layer of the finalize launch: about two per CU in all, 2..FG_G per layer
+    long long layers = 0;
+    for (int u : act) layers += hs[u]->g.L;
+    bt.fg = (int)std::max<long long>(2, std::min<long long>(FG_G, (2LL * h0->ncu) / std::max<long long>(1, layers)));
+  }
   for (size_t i = 0; i < act.size(); ++i) {
     vmr_ctx* h = hs[act[i]];
     const Geo& g = h->g;
     fu[i] = FinUnit{h->par, h->Hg, h->Cg, h->slotA, h->slotF, h->lutg, h->fin_g, h->nu_acc, h->slotR, bt.be + (size_t)act[i] * 8, g,
                     (int)gmap.size(), (int)rmap.size(), g.L * FR_G};
-    gmap.insert(gmap.end(), (size_t)g.L * FG_G, (int)i);
+    gmap.insert(gmap.end(), (size_t)g.L * bt.fg, (int)i);
     rmap.insert(rmap.end(), (size_t)g.L * FR_G, (int)i);
-    bt.fsm = std::max(bt.fsm, (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8);
+    bt.fsm = std::max(bt.fsm, (size_t)2 * ((g.M + bt.fg - 1) / bt.fg) * 8);
   }
   HIPCHK(h0, hipMemcpyAsync(bt.fu, fu.data(), fu.size() * sizeof(FinUnit), hipMemcpyHostToDevice, st));
   HIPCHK(h0, hipMemcpyAsync(bt.gmap, gmap.data(), gmap.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -3181,7 +3187,7 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
   int rc = batch_tables(hs, act, n, bt, st);
   if (rc) return rc;
   auto launch_sweeps = [&](int mode) -> int {
-    hipLaunchKernelGGL(k_fin_gamma_b, dim3(bt.ngb), dim3(FIN_TPB), bt.fsm, st, bt.fu, bt.gmap);
+    hipLaunchKernelGGL(k_fin_gamma_b, dim3(bt.ngb), dim3(FIN_TPB), bt.fsm, st, bt.fu, bt.gmap, bt.fg);
     int r = pass(h0, st, mode, allfull, bt.su[mode], bt.smap[mode], bt.nb[mode], bt.tpb[mode], bt.smem[mode]);
     if (r) return r;
     if (mode == 1) hipLaunchKernelGGL(k_fin_rho_b, dim3(bt.nrb), dim3(TPB), 0, st, bt.fu, bt.rmap);
