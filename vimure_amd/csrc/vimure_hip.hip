@@ -3051,11 +3051,14 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
   for (int u : act) steps += (((long long)hs[u]->g.N * hs[u]->g.N + 63) / 64) * hs[u]->g.L;
   std::vector<FinUnit> fu(act.size());
   std::vector<int> gmap, rmap;
+  const long long per_cap = getenv("VMR_BATCH_PER") ? atoll(getenv("VMR_BATCH_PER")) : 64;   // (experiments)
   for (int m = 0; m < 3; ++m) {
     const int tpb = sl_tpb_max_b(K, m == 1, allfull), nw = tpb / 64;
     // steps per wave: about one workgroup per CU in all (the tables in LDS allow few more, and a second round of workgroups
-    // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each
-    const long long per = std::max<long long>(4, std::min<long long>(64, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
+    // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each, at
+    // most 64 (192 fits of N = 200..800, lockstep loops: cap 8 1.05 s, 16 0.88, 32 0.78, 64 0.72, none 0.96 -- a small unit
+    // then is one workgroup that walks all its steps)
+    const long long per = std::max<long long>(4, std::min<long long>(per_cap, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
     std::vector<SlUnit> su(act.size());
     std::vector<int> map;
     size_t smem = 0;
