@@ -158,52 +158,54 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
     order = sorted(range(len(units)), key=lambda i: -float(units[i][1].shape[1]))   # similar sizes side by side
     from . import _hostlib
     cap_before, _hostlib.max_threads = _hostlib.max_threads, 1   # many draws side by side: one host thread each
-    with ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="vmr-draw") as ex:
-        for g0 in range(0, len(order), max(1, width)):
-            group = [units[i] for i in order[g0:g0 + max(1, width)]]
-            engs = timed("engines", lambda: list(ex.map(lambda u: _make_engine(u[1], u[2], K, mutuality, device, eps), group)))
-            try:
-                res = {u[0]: ([], []) for u in group}
-                for seed in seeds:
-                    t0 = time.perf_counter()
-                    fits = timed("prepare", lambda: list(ex.map(lambda ue: _LockstepFit(ue[0][1], ue[0][2], K, seed, mutuality, ue[1], fit_kwargs, need_rho=keep is not None or on_model is not None), zip(group, engs))))
-                    live = list(range(len(fits)))
-                    drawn = [ex.submit(fits[i].draw) for i in live]   # realisation 0
-                    while live:
-                        live = timed("draw+upload", lambda: [i for i, d in zip(live, drawn) if d.result()])
-                        if not live:
-                            break
-                        timed("draw+upload", lambda: list(ex.map(lambda i: fits[i].upload(), live)))
-                        drawn = [ex.submit(fits[i].draw) for i in live]   # the next realisation's draws run while this one sweeps
-                        m0 = fits[live[0]].m
-                        t1 = time.perf_counter()
-                        loops = CaviEngine.fit_loop_batch([engs[i] for i in live], m0.max_iter, m0.convergence_tol, m0.decision)
-                        dt = time.perf_counter() - t1
-                        clock["loops"] += dt
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="vmr-draw") as ex:
+            for g0 in range(0, len(order), max(1, width)):
+                group = [units[i] for i in order[g0:g0 + max(1, width)]]
+                engs = timed("engines", lambda: list(ex.map(lambda u: _make_engine(u[1], u[2], K, mutuality, device, eps), group)))
+                try:
+                    res = {u[0]: ([], []) for u in group}
+                    for seed in seeds:
+                        t0 = time.perf_counter()
+                        fits = timed("prepare", lambda: list(ex.map(lambda ue: _LockstepFit(ue[0][1], ue[0][2], K, seed, mutuality, ue[1], fit_kwargs, need_rho=keep is not None or on_model is not None), zip(group, engs))))
+                        live = list(range(len(fits)))
+                        drawn = [ex.submit(fits[i].draw) for i in live]   # realisation 0
+                        while live:
+                            live = timed("draw+upload", lambda: [i for i, d in zip(live, drawn) if d.result()])
+                            if not live:
+                                break
+                            timed("draw+upload", lambda: list(ex.map(lambda i: fits[i].upload(), live)))
+                            drawn = [ex.submit(fits[i].draw) for i in live]   # the next realisation's draws run while this one sweeps
+                            m0 = fits[live[0]].m
+                            t1 = time.perf_counter()
+                            loops = CaviEngine.fit_loop_batch([engs[i] for i in live], m0.max_iter, m0.convergence_tol, m0.decision)
+                            dt = time.perf_counter() - t1
+                            clock["loops"] += dt
 
-                        def end(il):
-                            fits[il[0]].m.loop_seconds += dt
-                            fits[il[0]].end(il[1][0], il[1][1])
-                        timed("pull", lambda: list(ex.map(end, zip(live, loops))))
-                    models = timed("finish", lambda: list(ex.map(lambda f: f.finish(), fits)))
-                    dt = (time.perf_counter() - t0) / max(1, len(fits))
-                    if on_model is not None:
-                        list(ex.map(lambda um: on_model(um[0][0], seed, um[1], dt), zip(group, models)))
-                    for u, m in zip(group, models):
-                        rows, kept = res[u[0]]
-                        rows.append({"layer": u[0], "seed": seed, "elbo": float(m.maxL),
-                                     "iters": int(m.trace["iter"].max()) if len(m.trace) else 0,
-                                     "converged": bool(m.trace["reached_convergence"].any()) if len(m.trace) else False,
-                                     "seconds": dt, "nu": float(m.G_exp_nu_f)})
-                        if keep == "all":
-                            kept.append((seed, m, dt))
-                        elif keep == "best" and (not kept or kept[0][1].maxL < m.maxL):
-                            kept[:] = [(seed, m, dt)]
-                out.update(res)
-            finally:
-                for e in engs:
-                    e.close()
-    _hostlib.max_threads = cap_before
+                            def end(il):
+                                fits[il[0]].m.loop_seconds += dt
+                                fits[il[0]].end(il[1][0], il[1][1])
+                            timed("pull", lambda: list(ex.map(end, zip(live, loops))))
+                        models = timed("finish", lambda: list(ex.map(lambda f: f.finish(), fits)))
+                        dt = (time.perf_counter() - t0) / max(1, len(fits))
+                        if on_model is not None:
+                            list(ex.map(lambda um: on_model(um[0][0], seed, um[1], dt), zip(group, models)))
+                        for u, m in zip(group, models):
+                            rows, kept = res[u[0]]
+                            rows.append({"layer": u[0], "seed": seed, "elbo": float(m.maxL),
+                                         "iters": int(m.trace["iter"].max()) if len(m.trace) else 0,
+                                         "converged": bool(m.trace["reached_convergence"].any()) if len(m.trace) else False,
+                                         "seconds": dt, "nu": float(m.G_exp_nu_f)})
+                            if keep == "all":
+                                kept.append((seed, m, dt))
+                            elif keep == "best" and (not kept or kept[0][1].maxL < m.maxL):
+                                kept[:] = [(seed, m, dt)]
+                    out.update(res)
+                finally:
+                    for e in engs:
+                        e.close()
+    finally:
+        _hostlib.max_threads = cap_before
     if os.environ.get("VMR_BATCH_TIMING"):
         print("fit_units_lockstep seconds:", {k: round(v, 3) for k, v in clock.items()}, flush=True)
     return out
