@@ -21,7 +21,7 @@
 #include <omp.h>
 #endif
 
-#define KMAX 16
+#define KMAX 256
 
 typedef struct {
   int L, N, M, K, mut;

@@ -9,7 +9,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if not n.startswith(("J_", "K_"))]   # J_*: ingestion vectors, K_*: generator vectors -- not model cases
+    # J_*: ingestion vectors, K_*: generator vectors, N_*: an input on which the reference raises -- not model cases
+    return [n for n in names if not n.startswith(("J_", "K_", "N_"))]
 
 
 def load_case(name):
@@ -18,8 +19,11 @@ def load_case(name):
         shape = tuple(int(s) for s in d["X_shape"])
         X = np.zeros(shape, np.uint8)
         X[tuple(d["X_subs"].astype(np.int64))] = d["X_vals"]
-        R = np.zeros(shape, np.uint8)
-        R[tuple(d["R_subs"].astype(np.int64))] = 1
+        if "R_subs" in d:
+            R = np.zeros(shape, np.uint8)
+            R[tuple(d["R_subs"].astype(np.int64))] = 1
+        else:   # (every reporter may report on every tie)
+            R = np.ones(shape, np.uint8)
         d["X"], d["R"] = X, R
     return d
 

@@ -79,14 +79,16 @@ def run_case(name, X, R, K, mutuality=True, undirected=False, seed=1, n_steps=3,
              rho_prior=None, priors=None, save_inputs=True):
     priors = priors or {}
     fit_kwargs = dict(fit_kwargs or {})
-    out = {"K": K, "mutuality": int(mutuality), "undirected": int(undirected), "seed": seed}
+    out = {"K": K if K is not None else int(X.max()) + 1, "K_given": int(K is not None), "mutuality": int(mutuality),
+           "undirected": int(undirected), "seed": seed}
     if save_inputs:
+        assert X.max() <= 255
         out["X"] = X.astype(np.uint8)
         out["R"] = R.astype(np.uint8)
-    assert X.max() <= 255
     # ---- step-level capture through the reference's private methods
     m = VimureModel(mutuality=mutuality, undirected=undirected)
-    m._VimureModel__check_fit_params(X=X.copy(), seed=seed, R=R.copy(), K=K, rho_prior=rho_prior, **priors)
+    kk = {} if K is None else {"K": K}   # (K omitted: the reference defaults to max(X) + 1, model.py:192-197)
+    m._VimureModel__check_fit_params(X=X.copy(), seed=seed, R=R.copy(), rho_prior=rho_prior, **kk, **priors)
     m._set_rho_prior()
     m._initialize_priors()
     m._initialize_old_variables()
@@ -106,7 +108,7 @@ def run_case(name, X, R, K, mutuality=True, undirected=False, seed=1, n_steps=3,
     out["step_elbo"] = np.array(elbos)
     # ---- a complete fit
     m2 = VimureModel(mutuality=mutuality, undirected=undirected)
-    m2.fit(X.copy(), R=R.copy(), K=K, seed=seed, rho_prior=rho_prior, **priors, **fit_kwargs)
+    m2.fit(X.copy(), R=R.copy(), seed=seed, rho_prior=rho_prior, **kk, **priors, **fit_kwargs)
     for n in ("gamma_shp_f", "gamma_rte_f", "phi_shp_f", "phi_rte_f", "nu_shp_f", "nu_rte_f", "rho_f",
               "G_exp_theta_f", "G_exp_lambda_f", "G_exp_nu_f"):
         out["fit_" + n] = np.array(getattr(m2, n), dtype=np.float64)
@@ -245,10 +247,72 @@ def io_cases():
     print("J_edgelist_io: rows", len(df), "vil1 rows", len(kdf), "vil1 LNMK", out["vil1_LNMK"])
 
 
+def wide_cases():
+    """Inputs beyond K = 8 and beyond one-byte counts: the reference's DEFAULT K = max(X) + 1 (model.py:179-197, exercised by
+    test/test_model.py:59-115) and counts in the thousands (edgelist weights summed per (reporter, tie), utils.py:241-242)."""
+    # L: K omitted -> K = max(X) + 1 = 12; random mask, mutuality on.  Counts 1..11 on top of a sparse base.
+    X, R = synth(1, 18, 8, 0.4, 21, mask="random", density=0.10)
+    g = np.random.RandomState(77)
+    nz = np.nonzero(X)
+    pick = g.choice(len(nz[0]), size=len(nz[0]) // 3, replace=False)
+    X[nz[0][pick], nz[1][pick], nz[2][pick], nz[3][pick]] += g.randint(1, 11, size=len(pick))
+    X = np.minimum(X, 11)
+    X[0, 2, 3, 1] = 11
+    R[0, 2, 3, 1] = 1
+    run_case("L_default_K12", X, R, None, seed=2, n_steps=2, fit_kwargs=dict(num_realisations=2, max_iter=30))
+    # M: two layers, K = 16 given, all-ones mask, mutuality off
+    X, R = synth(2, 14, 6, 0.0, 22, density=0.12)
+    X = X * g.randint(1, 4, size=X.shape)
+    run_case("M_K16_nomut", X, R, 16, mutuality=False, seed=4, n_steps=2, fit_kwargs=dict(num_realisations=1, max_iter=20))
+    # N: K = 2 with counts up to 12000 (int64 in the reference, utils.py:241-242), self-reporter mask.  The reference accepts the
+    #    tensor and then fails on its own arithmetic: x (E log theta + E log lambda) passes 709, the raw exponentials of the rho
+    #    update (model.py:807) overflow, inf / inf = NaN, and the first ELBO check raises "ELBO is NaN!!!!" (model.py:1016).
+    #    Recorded: the inputs and the error, which the engine has to reproduce (it accepts the counts, then raises the same).
+    X, R = synth(1, 16, 16, 0.3, 23, mask="self", density=0.2, outside=6)
+    nz = np.nonzero(X)
+    pick = g.choice(len(nz[0]), size=len(nz[0]) // 2, replace=False)
+    X[nz[0][pick], nz[1][pick], nz[2][pick], nz[3][pick]] *= g.randint(2, 4000, size=len(pick))
+    X[0, 1, 2, 1] = 12000
+    R[0, 1, 2, 1] = 1
+    err = ""
+    try:
+        VimureModel().fit(X.copy(), R=R.copy(), K=2, seed=6, num_realisations=1, max_iter=20)
+    except ValueError as e:
+        err = str(e)
+    xs, rs = np.nonzero(X), np.nonzero(R)
+    np.savez_compressed(os.path.join(OUT, "N_counts_12000.npz"), K=2, seed=6, error=np.array(err), X_shape=np.array(X.shape),
+                        X_subs=np.stack(xs).astype(np.int16), X_vals=X[xs].astype(np.int32), R_subs=np.stack(rs).astype(np.int16))
+    print(f"N_counts_12000: nnzX={len(xs[0])} max={X.max()} reference raised: {err!r}")
+    # O: many reporters and counts to 130: (max + 1) * M passes the 2^20 table rows of a packed entry; mutuality on, all finite
+    #    (a count of 250 already overflows the reference's exponentials)
+    L_, N_, M_ = 1, 5, 8190
+    g2 = np.random.RandomState(31)
+    X = np.zeros((L_, N_, N_, M_), np.int64)
+    R = np.ones_like(X)
+    for _ in range(160):
+        i, j = g2.randint(N_, size=2)
+        if i != j:
+            X[0, i, j, g2.randint(M_)] = g2.randint(1, 4)
+    X[0, 1, 2, 7] = 130
+    X[0, 2, 1, 7] = 3
+    X[0, 3, 4, 8189] = 60
+    run_case("O_wide_rows", X, R, 2, seed=8, n_steps=2, save_inputs=False, fit_kwargs=dict(num_realisations=1, max_iter=20))
+    path = os.path.join(OUT, "O_wide_rows.npz")
+    d = dict(np.load(path))
+    xs = np.nonzero(X)
+    d.update({"X_shape": np.array(X.shape), "X_subs": np.stack(xs).astype(np.int16), "X_vals": X[xs].astype(np.int32)})
+    np.savez_compressed(path, **d)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "io":
     io_cases()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "wide":
+    os.makedirs(OUT, exist_ok=True)
+    wide_cases()
 
 
 if __name__ == "__main__" and len(sys.argv) == 1:
     main()
     io_cases()
+    wide_cases()

@@ -866,11 +866,10 @@ int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlAr
 template <bool UPDATE, bool ELBO, bool ALLFULL>
 static int sl_launch_batch_one(vmr_ctx* h, hipStream_t st, const SlUnit* units, const int* blk_unit, int nblocks, int tpb, size_t smem) {
   constexpr int K = VMR_K;
-  static size_t attr = 48 * 1024;   // (largest dynamic LDS size this kernel has been given leave for)
-  if (smem > attr) {
+  // (the leave for > 48 KB of dynamic LDS is per device and this may be any thread's first launch there: asked for every time --
+  // a call that costs nothing beside a batch's launches -- instead of remembered in a process-wide static)
+  if (smem > 48 * 1024)
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = smem;
-  }
   hipLaunchKernelGGL((k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
   return VMR_OK;
 }

@@ -2888,6 +2888,9 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
+  // (queued before the wait: the lockstep loop runs this handle's kernels on another handle's stream, so nothing of this call
+  // may still be pending on the handle's own stream when it returns)
+  HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
   h->restored = false;
@@ -2895,7 +2898,6 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   h->f_valid = false;
   h->a_valid = false;
   h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
-  HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   return VMR_OK;
 }
 
@@ -3144,7 +3146,13 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
   }
   if (act.size() < 2 || max_iter < 2) { for (int u : act) solo(u); return finish(); }
   vmr_ctx* h0 = hs[act[0]];
+  // Every failure from here on leaves through ONE exit: the code goes into rc_out of every unit still in the lockstep loop (their
+  // traces, ELBOs and iteration counts are then meaningless) and into the return value.
+  auto lockstep = [&]() -> int {
   HIPCHK(h0, hipSetDevice(h0->device));
+  // the loop runs every unit's kernels on ONE stream (the first unit's): whatever a unit's own stream still holds -- the tail of
+  // vmr_set_state, an earlier sweep -- is waited for here, once
+  for (int u : act) HIPCHK(h0, hipStreamSynchronize(hs[u]->stream));
   // Iteration 1 (the ELBO is evaluated there, model.py:1036) also builds the statistics of the initial rho -- launches the
   // steady sweeps do not have.  Handles that come straight from vmr_set_state take it inside the tables (below); if some do
   // not, every handle runs it on its own stream.
@@ -3164,7 +3172,7 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
       ++i;
     }
   }
-  if (act.size() < 2) { for (int u : act) solo(u); return finish(); }
+  if (act.size() < 2) { for (int u : act) solo(u); act.clear(); return VMR_OK; }
   h0 = hs[act[0]];
   hipStream_t st = h0->stream;
   const int K = h0->g.K, allfull = h0->all_full != 0;
@@ -3249,7 +3257,13 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
     if (changed && !act.empty() && it <= max_iter && (rc = batch_tables(hs, act, n, bt, st))) break;
   }
   (void)hipStreamSynchronize(st);
-  if (rc) { for (int u : act) if (!rc_out[u]) rc_out[u] = rc; }
+  return rc;
+  };
+  const int rc_all = lockstep();
+  if (rc_all) {
+    (void)hipStreamSynchronize(h0->stream);
+    for (int u : act) if (!rc_out[u]) { rc_out[u] = rc_all; if (hs[u] != h0) hs[u]->err = h0->err; }
+  }
   return finish();
 }
 

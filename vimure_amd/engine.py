@@ -251,11 +251,15 @@ class CaviEngine:
         e = np.zeros(n)
         ri, rr = np.empty((n, cap), np.int32), np.empty((n, cap), np.int32)
         re, rt = np.empty((n, cap)), np.empty((n, cap))
-        lib.vmr_fit_loop_batch(hs, n, int(max_iter), float(tol), int(decision), cap, nr.ctypes.data, ri.ctypes.data, re.ctypes.data,
-                               rt.ctypes.data, rr.ctypes.data, e.ctypes.data, its.ctypes.data, conv.ctypes.data, rcs.ctypes.data)
+        rc = lib.vmr_fit_loop_batch(hs, n, int(max_iter), float(tol), int(decision), cap, nr.ctypes.data, ri.ctypes.data,
+                                    re.ctypes.data, rt.ctypes.data, rr.ctypes.data, e.ctypes.data, its.ctypes.data,
+                                    conv.ctypes.data, rcs.ctypes.data)
         out = []
         for u, eng in enumerate(engines):
             eng._check(int(rcs[u]))
+        if rc != 0:   # (a failure before the per-unit codes were written: argument checks)
+            engines[0]._check(int(rc))
+        for u, eng in enumerate(engines):
             k = int(nr[u])
             out.append((list(zip(ri[u, :k].tolist(), re[u, :k].tolist(), rt[u, :k].tolist(), [bool(v) for v in rr[u, :k]])),
                         float(e[u]), int(its[u]), bool(conv[u])))

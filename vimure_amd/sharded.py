@@ -45,7 +45,8 @@ def fit_layer_sharded(X_local, R_local, local_layers, L_total, K, dist, seed=Non
     if on_dev:
         import torch
         ext = torch.cuda.ExternalStream(eng.stream_ptr(), device=torch.device(red_dev))
-        buf = torch.zeros(3, dtype=torch.float64, device=red_dev)
+        with torch.cuda.stream(ext):   # (filled on the stream every later use of it is queued on: the engine's own)
+            buf = torch.zeros(3, dtype=torch.float64, device=red_dev)
     Ll, N, M = eng.L, eng.N, eng.M
     assert Ll == len(local_layers)
     try:
