@@ -17,8 +17,10 @@ def _fit(d, X=None, R=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = VimureModel(mutuality=bool(d["mutuality"]), undirected=und)
-        m.fit(d["X"] if X is None else X, R=d["R"] if R is None else R, K=K, seed=seed, rho_prior=rho_prior,
-              **priors, **fitargs)
+        kk = {"K": K} if int(d.get("K_given", 1)) else {}   # (K omitted: the reference's default K = max(X) + 1, model.py:179-197)
+        m.fit(d["X"] if X is None else X, R=d["R"] if R is None else R, seed=seed, rho_prior=rho_prior,
+              **kk, **priors, **fitargs)
+        assert m.K == K
     return m
 
 

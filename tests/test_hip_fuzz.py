@@ -14,3 +14,12 @@ def test_random_cases_match_the_oracle(seed):
     g = np.random.RandomState(seed)
     bad = [i for i in range(30) if not one(i, g)]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", [3])
+def test_random_cases_beyond_eight_categories_and_byte_counts(seed):
+    """K in {2, 3, 9, 12, 16, 21, 33, 70} and counts to 3000 (two-word entries): the general kernels against the same oracle."""
+    from tools.fuzz_parity import one
+    g = np.random.RandomState(seed)
+    bad = [i for i in range(30) if not one(i, g, wide=True)]
+    assert not bad, bad

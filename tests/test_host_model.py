@@ -50,10 +50,18 @@ def test_bad_mask_shape():
         VimureModel().fit(X, R=R[:, :, :, :-1], K=2)
 
 
-def test_counts_above_255_rejected():
+def test_counts_beyond_a_byte_become_coordinate_lists():
+    """The reference holds int64 counts (utils.py:241-242): a dense array whose counts pass 255 reaches the engine as its
+    coordinate lists (vmr_create_coo takes any count below 2^31); only what no layout holds is refused on the host."""
+    from vimure_amd.tensor import engine_data, is_sparse_like
     X, R = small()
-    with pytest.raises(ValueError, match="255"):
-        VimureModel().fit(X.astype(np.int64) * 300, R=R, K=2)
+    big = engine_data(X.astype(np.int64) * 300)
+    assert is_sparse_like(big) and int(big.vals.max()) == int(X.max()) * 300 and tuple(big.shape) == X.shape
+    assert engine_data(X).dtype == np.uint8
+    with pytest.raises(ValueError, match="2\\^31"):
+        VimureModel().fit(X.astype(np.int64) * (2 ** 31), R=R, K=2)
+    with pytest.raises(ValueError, match="M <= 8192"):
+        engine_data(np.full((1, 2, 2, 9000), 300, np.int64))
 
 
 def test_missing_k_and_r_warn_then_engine_refuses_without_gpu():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): random shapes, K, mutuality, mask kinds, count ranges and engine shapes against the
-coordinate-list oracle -- three sweeps with the ELBO each, state compared at the end.  `python tools/fuzz_parity.py [n] [seed]`."""
+coordinate-list oracle -- three sweeps with the ELBO each, state compared at the end.  `python tools/fuzz_parity.py [n] [seed] [wide]`."""
 import os
 import sys
 import time
@@ -11,17 +11,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PRI = (0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
 
 
-def one(case, g):
+def one(case, g, wide=False):
+    """wide: the inputs beyond the specialised kernels -- K up to 70 (the reference's default K = max(X) + 1 gives such K) and counts
+    beyond 11 bits / table rows beyond 2^20 (two-word entries) -- which the general kernels (csrc/sweep_gen.hip) take."""
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     L = int(g.choice([1, 1, 2, 3]))
-    N = int(g.choice([5, 17, 33, 64, 65, 100, 130]))
+    N = int(g.choice([5, 17, 33, 64, 65, 100, 130] if not wide else [5, 17, 33, 64, 65]))
     M = int(g.choice([1, 3, 16, 17, 40, 64, 65, 130]))
-    K = int(g.choice([2, 2, 2, 3, 3, 4, 5, 8]))
+    K = int(g.choice([2, 2, 2, 3, 3, 4, 5, 8] if not wide else [2, 3, 9, 12, 16, 21, 33, 70]))
     mut = bool(g.rand() < 0.7)
     dens = float(g.choice([0.01, 0.05, 0.2, 0.5]))
-    xmax = int(g.choice([1, 3, 10, 63]))
-    X = ((g.rand(L, N, N, M) < dens) * g.randint(1, xmax + 1, size=(L, N, N, M))).astype(np.uint8)
+    xmax = int(g.choice([1, 3, 10, 63] if not wide else [3, 40, 120, 255, 3000]))
+    X = ((g.rand(L, N, N, M) < dens) * g.randint(1, xmax + 1, size=(L, N, N, M))).astype(np.uint8 if xmax <= 255 else np.int32)
     mk = g.choice(["ones", "none", "random", "sparse", "self"])
     if mk == "none":
         R = None
@@ -52,7 +54,7 @@ def one(case, g):
     os.environ.update(env)
     desc = f"case {case}: L{L} N{N} M{M} K{K} mut={int(mut)} dens={dens} xmax={xmax} mask={mk} env={env}"
     try:
-        use_coo = fmt != "dense" and xmax <= 63 and M <= 8192 and g.rand() < 0.4   # the coordinate-list entry point (vmr_create_coo)
+        use_coo = M <= 8192 and (xmax > 255 or (fmt != "dense" and g.rand() < 0.4))   # the coordinate-list entry point (vmr_create_coo)
         if use_coo:
             desc += " [coo]"
         try:
@@ -61,9 +63,9 @@ def one(case, g):
                 eng = CaviEngine.from_coo(sx0, X[sx0], X.shape, R=None if R is None else np.nonzero(R), K=K, mutuality=mut, device=0)
             else:
                 eng = CaviEngine(X, R, K=K, mutuality=mut, device=0)
-        except ValueError as e:   # a refused combination (e.g. sparse forced with counts the lists cannot hold)
+        except ValueError as e:   # a refused combination: the dense tiles forced beyond 8 categories
             print(desc, "-> refused:", str(e)[:80], flush=True)
-            return True
+            return fmt == "dense" and K > 8 and not use_coo
         sum_x, cov = eng.data_stats()
         gs = np.random.RandomState(case)
         pr = gs.rand(L, N, N, K) + 0.05
@@ -116,9 +118,10 @@ def one(case, g):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
     g = np.random.RandomState(seed)
     t0 = time.time()
-    bad = sum(0 if one(i, g) else 1 for i in range(n))
+    bad = sum(0 if one(i, g, wide) else 1 for i in range(n))
     print(f"{n} cases, {bad} failed, {time.time() - t0:.0f} s", flush=True)
     sys.exit(1 if bad else 0)
 

@@ -24,7 +24,7 @@ import pandas as pd
 
 from .engine import CaviEngine
 from .model import VimureModel
-from .tensor import is_sparse_like, layer_of, to_dense_u8
+from .tensor import engine_data, is_sparse_like, layer_of, to_dense_u8
 
 DEFAULT_WORKERS = 8
 
@@ -213,9 +213,9 @@ def fit_units_lockstep(units, K, seeds, mutuality, device, fit_kwargs, workers=D
 
 def _as_data(X, R):
     """Coordinate containers stay as they are (when the report lists can hold them); everything else becomes dense uint8."""
-    if is_sparse_like(X) and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 2047)):
-        return X, R
-    Xd = to_dense_u8(X, "X")
+    Xd = engine_data(X, "X")
+    if is_sparse_like(Xd):
+        return Xd, R
     Rd = None if R is None else (to_dense_u8(R, "R") != 0).astype(np.uint8)
     return Xd, Rd
 

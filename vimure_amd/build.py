@@ -15,7 +15,8 @@ LIB = os.environ.get("VMR_LIB_OUT", os.path.join(HERE, "libvimure_hip.so"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HOST_SRC = os.path.join(CSRC, "host_init.c")
 HOST_LIB = os.path.join(HERE, "libvimure_host.so")
-HEADERS = [os.path.join(CSRC, "vmr_internal.h"), os.path.join(CSRC, "sweep_sl.h"), os.path.join(ROOT, "include", "vimure_hip.h")]
+HEADERS = [os.path.join(CSRC, "vmr_internal.h"), os.path.join(CSRC, "sweep_sl.h"), os.path.join(CSRC, "sweep_gen.h"),
+           os.path.join(ROOT, "include", "vimure_hip.h")]
 KS = (2, 3, 4, 5, 6, 7, 8)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -24,7 +25,8 @@ def units(dev=False):
     """(object name, source, extra flags) of every translation unit."""
     extra = ["-DVMR_DEV"] if dev else []
     u = [("vimure_hip", os.path.join(CSRC, "vimure_hip.hip"), extra),
-         ("sorted_lists", os.path.join(CSRC, "sorted_lists.hip"), extra)]
+         ("sorted_lists", os.path.join(CSRC, "sorted_lists.hip"), extra),
+         ("sweep_gen", os.path.join(CSRC, "sweep_gen.hip"), extra)]   # the general kernels: any K, wide entries
     dev_ks = tuple(int(k) for k in os.environ.get("VMR_DEV_KS", "2").split(","))   # (VMR_DEV_KS=2,3: also the K = 3 sweep kernels)
     for k in (dev_ks if dev else KS):
         u.append((f"sweep_sl_k{k}", os.path.join(CSRC, "sweep_sl.hip"), extra + [f"-DVMR_K={k}"]))

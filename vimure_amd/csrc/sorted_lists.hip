@@ -17,9 +17,12 @@ __global__ __launch_bounds__(256) void k_sl_steps(const unsigned* __restrict__ k
   if (blockIdx.x == 0 && threadIdx.x == 0) sz[NS] = 0u;
 }
 // one wave per step: lane <-> position; round r of the step = the r-th entry of every tie (0 where it has fewer)
+// (wide entries, Geo::wide: Ein2 / Eout2 carry the second word of every entry through the same placement; the first word is then
+// the table row itself)
 __global__ __launch_bounds__(256) void k_sl_place(const unsigned* __restrict__ perm, const unsigned* __restrict__ rpl /*scanned, by tie*/,
                                                   const unsigned* __restrict__ rsl, const unsigned* __restrict__ Ein,
-                                                  unsigned* __restrict__ Eout, unsigned* __restrict__ syl, size_t T, size_t NS, int Mp) {
+                                                  unsigned* __restrict__ Eout, const unsigned* __restrict__ Ein2, unsigned* __restrict__ Eout2,
+                                                  unsigned* __restrict__ syl, size_t T, size_t NS, int Mp) {
   const int lane = threadIdx.x & 63;
   for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
     const unsigned t = perm[s * 64 + lane];
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(256) void k_sl_place(const unsigned* __restrict__ p
       if (q >= n) q -= n;
       const unsigned e = n > r ? Ein[(size_t)r0 + q] : 0u;
       Eout[(size_t)ea + r * 64 + lane] = e;
-      ymx = max(ymx, SL_YM(e) / (unsigned)Mp);
+      if (Ein2) Eout2[(size_t)ea + r * 64 + lane] = n > r ? Ein2[(size_t)r0 + q] : 0u;
+      ymx = max(ymx, (Ein2 ? e : SL_YM(e)) / (unsigned)Mp);
     }
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) ymx = max(ymx, (unsigned)__shfl_xor((int)ymx, o2, 64));
@@ -87,13 +91,14 @@ int sl_permute_rows(vmr_ctx* h, const double* in, double* out, bool to_pos) {
   return VMR_OK;
 }
 
-int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, const SlFill* fill) {
+int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, unsigned* etmp2_all, const SlFill* fill) {
   Geo& g = h->g;
   const int L = g.L;
   const size_t T = (size_t)g.N * g.N, n = T + 1, NS = (T + 63) / 64;
-  unsigned *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *bsum = nullptr, *etmp = nullptr;
+  unsigned *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *bsum = nullptr, *etmp = nullptr, *etmp2 = nullptr;
   void* tmp = nullptr;
-  auto cleanup = [&]() { void* p[] = {keys, keys2, vals, vals2, bsum, etmp, tmp}; for (void* q : p) if (q) (void)hipFree(q); };
+  const bool wide = g.wide != 0;
+  auto cleanup = [&]() { void* p[] = {keys, keys2, vals, vals2, bsum, etmp, etmp2, tmp}; for (void* q : p) if (q) (void)hipFree(q); };
 #define CKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); cleanup(); return VMR_EHIP; } } while (0)
   if (T >= 0x7fffffffull) return fail(nullptr, VMR_EINVAL, "more than 2^31 ties in one layer");
   CKS(hipMalloc(&keys, T * 4)); CKS(hipMalloc(&keys2, T * 4)); CKS(hipMalloc(&vals, T * 4)); CKS(hipMalloc(&vals2, T * 4));
@@ -131,17 +136,23 @@ int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long l
   CKS(hipMemcpy(h->ebase, eb.data(), (size_t)L * 8, hipMemcpyHostToDevice));
   CKS(hipMalloc(&h->E, ((size_t)h->n_slots + SL_SLACK) * 4));
   CKS(hipMemsetAsync(h->E + h->n_slots, 0, (size_t)SL_SLACK * 4, h->stream));
+  if (wide) {
+    CKS(hipMalloc(&h->EX, ((size_t)h->n_slots + SL_SLACK) * 4));
+    CKS(hipMemsetAsync(h->EX + h->n_slots, 0, (size_t)SL_SLACK * 4, h->stream));
+  }
   if (!etmp_all) {
     unsigned long long nlmax = 0;
     for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
     CKS(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
+    if (wide) CKS(hipMalloc(&etmp2, ((size_t)nlmax + 64) * 4));
   }
   unsigned long long off = 0;
   for (int l = 0; l < L; ++l) {
     unsigned* src = etmp_all ? etmp_all + off : etmp;
-    if (!etmp_all) (*fill)(l, rp + (size_t)l * n, etmp);
+    unsigned* src2 = wide ? (etmp_all ? etmp2_all + off : etmp2) : nullptr;
+    if (!etmp_all) (*fill)(l, rp + (size_t)l * n, etmp, etmp2);
     hipLaunchKernelGGL(k_sl_place, dim3(sgrid), dim3(256), 0, h->stream, h->perm + (size_t)l * NS * 64, rp + (size_t)l * n,
-                       h->rs + (size_t)l * (NS + 1), src, h->E + eb[l], h->sy + (size_t)l * NS, T, NS, g.Mp);
+                       h->rs + (size_t)l * (NS + 1), src, h->E + eb[l], src2, wide ? h->EX + eb[l] : nullptr, h->sy + (size_t)l * NS, T, NS, g.Mp);
     off += nl[l];
   }
   CKS(hipGetLastError());

@@ -1,0 +1,468 @@
+// sweep_gen.hip -- the general CAVI kernels (sweep_gen.h): any K in [2, KGEN_MAX], packed or wide entries.
+//
+//   k_sweep_gen      one pass over the sorted report lists: the rho update (model.py:763-818, 889-923), the statistics
+//                    H[l][y][m][k] = sum x rho_k of the new rho (what gamma / phi / nu are finished from: model.py:698-761, 820-887),
+//                    the sums of rho over mask rows (model.py:704-718, 742-749) and the ELBO's data terms (model.py:948-995)
+//   k_fin_gamma_gen  gamma, then phi, from H and the mask sums (model.py:698-761)
+//   k_fin_phi_gen    the PHI sub-step's commit (mutuality on)
+//   k_sample_gen     vmr_sample for K > KMAX
+// nu and the ELBO's assembly: k_fin_rho (vimure_hip.hip), which reads this file's single-copy H directly.
+//
+// A tie is spread over G = min(64, 2^ceil(log2 K)) lanes, one category per lane (NCH = ceil(K / 64) per lane beyond 64): the sum
+// over categories that normalises rho and the ELBO's inner sums are shuffles inside the group, the adds into H land on K
+// consecutive doubles.  The factor of a report, F = (E log theta_m + E log lambda_k) w1_k(m, y), is computed where it is used.
+#include "sweep_gen.h"
+
+struct GenArgs {
+  const unsigned *E, *EX, *rs;
+  const unsigned long long* ebase;
+  const unsigned* perm;
+  const uint8_t* cls;          // by position; null: every mask row is all ones
+  const unsigned* Qt;          // by position
+  const uint64_t* Rb; const unsigned* rq; const unsigned short* Rm; const unsigned long long* rbase;   // partial mask rows, by tie
+  double* rho; const double* logpr; const double* par;
+  double *slotR, *Hg, *slotF, *slotA;
+  int Gl, update, elbo, hist, sum_a;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
+  __shared__ double red[16];
+  __shared__ double s_tfull;
+  const int K = g.K, Mp = g.Mp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
+  int lg = 1;
+  while ((1 << lg) < K && lg < 6) ++lg;
+  const int G = 1 << lg, kk = lane & (G - 1), grp = lane >> lg, TPW = 64 >> lg;   // lanes per tie, this lane's category, its tie of the TPW in flight
+  const int l = (int)blockIdx.x / a.Gl, gb = (int)blockIdx.x - l * a.Gl;
+  const ParOff o = par_off(g.L, Mp, K);
+  const size_t T = (size_t)g.N * g.N;
+  const long long NS = (long long)((T + 63) / 64);
+  const double* Gth = a.par + o.G_th + (size_t)l * Mp;
+  const double* Lth = a.par + o.l_th + (size_t)l * Mp;
+  const double* Eth = a.par + o.E_th + (size_t)l * Mp;
+  {   // T of an all-ones mask row: sum_m E[theta_m] (model.py:766-792)
+    double tf = 0.0;
+    for (int m = tid; m < g.M; m += (int)blockDim.x) tf += Eth[m];
+    tf = block_sum_n(tf, red);
+    if (tid == 0) s_tfull = tf;
+    __syncthreads();
+  }
+  const double Tfull = s_tfull;
+  double Ela[NCH], Gla[NCH], Lla[NCH];
+  bool kv[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * G + kk;
+    kv[c] = k < K;
+    Ela[c] = kv[c] ? a.par[o.E_la + l * K + k] : 0.0;
+    Gla[c] = kv[c] ? a.par[o.G_la + l * K + k] : 0.0;
+    Lla[c] = kv[c] ? a.par[o.l_la + l * K + k] : 0.0;
+  }
+  const double gnu_f = a.par[o.sc + SC_G_NU];                                    // the cache refresh before the rho update (model.py:651)
+  const double gnu_e = a.par[o.sc + (a.update ? SC_G_NU : SC_G_NU_STALE)];      // the ELBO's: the stale one (model.py:970)
+  const double eps = g.eps;
+  const unsigned* rsl = a.rs + (size_t)l * (NS + 1);
+  const unsigned* El = a.E + a.ebase[l];
+  const unsigned* EXl = a.EX ? a.EX + a.ebase[l] : nullptr;
+  const unsigned* pl = a.perm + (size_t)l * NS * 64;
+  const uint8_t* cl = a.cls ? a.cls + (size_t)l * T : nullptr;
+  const unsigned* Ql = a.Qt ? a.Qt + (size_t)l * T : nullptr;
+  const uint64_t* Rl = a.Rb ? a.Rb + (size_t)l * T * g.W : nullptr;
+  const unsigned* rql = a.rq ? a.rq + (size_t)l * (T + 1) : nullptr;
+  const unsigned short* Rml = a.rq ? a.Rm + a.rbase[l] : nullptr;
+  double* rl = a.rho + (size_t)l * T * K;
+  const double* lpl = a.logpr + (size_t)l * T * K;
+  double* Hl = a.Hg + (size_t)l * g.Y * Mp * K;
+  double* Al = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
+  auto entry = [&](size_t slot, unsigned& ym, unsigned& x, unsigned& inr) {
+    const unsigned e = El[slot];
+    if (EXl) { const unsigned e2 = EXl[slot]; ym = e; x = e2 >> 1; inr = e2 & 1u; }
+    else { ym = SL_YM(e); x = SL_X(e); inr = SL_INR(e); }
+  };
+  // the reporters of a partial mask row: f(m) for every m with R[l, tie, m] = 1
+  auto for_reporters = [&](unsigned tie, auto&& f) {
+    if (rql) {
+      const unsigned q0 = rql[tie], q1 = rql[tie + 1];
+      for (unsigned q = q0; q < q1; ++q) f((int)Rml[q]);
+    } else if (Rl) {
+      const uint64_t* rw = Rl + (size_t)tie * g.W;
+      for (int w = 0; w < g.W; ++w) {
+        uint64_t bits = rw[w];
+        while (bits) { const int b = __builtin_ctzll(bits); bits &= bits - 1; f(w * 64 + b); }
+      }
+    }
+  };
+  double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
+  double accF[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) accF[c] = 0.0;
+
+  for (long long s = (long long)gb * nw + wv; s < NS; s += (long long)a.Gl * nw) {
+    const unsigned ea = rsl[s];
+    const int R = (int)((rsl[s + 1] - ea) >> 6);
+    for (int sub = 0; sub < G; ++sub) {   // the step's 64 ties, TPW at a time
+      const int pi = sub * TPW + grp;
+      const size_t pos = (size_t)s * 64 + pi;
+      const bool act = pos < T;
+      const unsigned cls = act ? (cl ? (unsigned)cl[pos] : 1u) : 0u;
+      const unsigned tie = (act && cls == 2u) ? pl[pos] : 0u;
+      double lp[NCH], r[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bool on = act && kv[c];
+        lp[c] = (on && (a.update || a.elbo)) ? lpl[pos * K + (c * G + kk)] : 0.0;
+        r[c] = (on && !a.update) ? rl[pos * K + (c * G + kk)] : 0.0;
+      }
+      double Tt = 0.0;   // sum_m R[tie, m] E[theta_m]
+      if (a.update || a.elbo) {
+        if (cls == 1u) Tt = Tfull;
+        else if (cls == 2u) for_reporters(tie, [&](int m) { Tt += Eth[m]; });
+      }
+      const size_t e0 = (size_t)ea + (unsigned)pi;
+      if (a.update) {
+        double U[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) U[c] = 0.0;
+        for (int rr = 0; rr < R; ++rr) {
+          unsigned ym, x, inr;
+          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          if (x != 0u) {
+            const unsigned y = ym / (unsigned)Mp, m = ym - y * (unsigned)Mp;
+            const double lt = Lth[m], gt = Gth[m], dx = (double)x;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+              if (kv[c]) U[c] = fma(dx, f_entry(g.mut, lt, gt, Lla[c], Gla[c], gnu_f, (int)y), U[c]);
+          }
+        }
+        double sl = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          r[c] = kv[c] ? exp((lp[c] + U[c]) - Tt * Ela[c]) : 0.0;   // raw exponentials, no max-subtraction (model.py:807)
+          sl += r[c];
+        }
+        const double sum = group_sum(sl, G);
+        if (sum > 0.0) {   // model.py:808-811: rows whose exponentials all underflow stay all zero
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) r[c] /= sum;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (!act) r[c] = 0.0;
+          if (act && kv[c]) rl[pos * K + (c * G + kk)] = r[c];
+        }
+      }
+      if ((a.update || a.hist) && act && cls == 1u) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) accF[c] += r[c];
+      }
+      if (a.sum_a && act && cls == 2u) {
+        for_reporters(tie, [&](int m) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if (kv[c]) atomicAdd(&Al[(size_t)m * K + (c * G + kk)], r[c]);
+        });
+      }
+      if (a.hist) {
+        for (int rr = 0; rr < R; ++rr) {
+          unsigned ym, x, inr;
+          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          if (x != 0u && act) {
+            double* hrow = Hl + (size_t)ym * K;
+            const double dx = (double)x;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+              if (kv[c]) atomicAdd(&hrow[c * G + kk], dx * r[c]);
+          }
+        }
+      }
+      if (a.elbo) {
+        double er[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) er[c] = kv[c] ? exp(r[c]) : 0.0;   // exp(rho), model.py:971
+        for (int rr = 0; rr < R; ++rr) {   // (every lane walks every round: the group sums are shuffles)
+          unsigned ym, x, inr;
+          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          const unsigned y = ym / (unsigned)Mp, m = ym - y * (unsigned)Mp;
+          const double z2 = gnu_e * (double)y, gt = Gth[m];
+          double il = 0.0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if (kv[c]) il += er[c] * (gt * Gla[c] + z2);
+          const double inner = group_sum(il, G);
+          if (kk == 0 && x != 0u && act) e_log += (double)x * log((inr ? inner : 0.0) + eps);   // eps alone outside R (model.py:990-994)
+        }
+        if (act) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            if (kv[c]) {
+              e_lin += r[c] * lp[c] - r[c] * log(r[c] + eps) - r[c] * Ela[c] * Tt;   // model.py:1306-1313, 975-985
+              if (Ql) e_q += r[c] * (double)Ql[pos];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.update || a.hist) {   // rho summed over the all-ones mask rows: lanes of equal category across the wave's groups
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      double v = accF[c];
+      for (int o2 = G; o2 < 64; o2 <<= 1) v += __shfl_xor(v, o2, 64);
+      if (grp == 0 && kv[c] && v != 0.0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + (c * G + kk)], v);
+    }
+  }
+  if (a.elbo) {
+    const double v1 = wave_sum(e_lin), v2 = wave_sum(e_log), v3 = wave_sum(e_q);
+    if (lane == 0) {
+      double* out = a.slotR + (size_t)(blockIdx.x % NSLOT) * 4;
+      atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: gamma, phi
+// ------------------------------------------------------------------------------------------
+// One workgroup per layer.  gamma_shp[m] = alpha + sum_{y,k} w1_k(m,y) H (old parameters; model.py:698-703, 832-859),
+// gamma_rte[m] = beta + sum_k E[lambda_k] A[m,k] (model.py:704-718), then with the NEW theta: phi_rte[k] = beta + sum_m E[theta_m] A[m,k]
+// (model.py:742-749) and phi_shp[k] = alpha + sum_{m,y} w1_k(m,y) H (model.py:731-733, 861-887); A[m,k] = the pass' sums of rho over
+// the mask rows holding m (all-ones rows: slotF).  consume: H, slotF are left zeroed for the next pass; slotA always is.
+__global__ __launch_bounds__(256) void k_fin_gamma_gen(double* par, double* Hg, double* slotA, double* slotF, double* s1g, int do_phi, int consume, Geo g) {
+  extern __shared__ double dyn[];   // fk | ela_old | gla_old | prs | pss, K each
+  const int K = g.K, Mp = g.Mp, M = g.M, l = blockIdx.x, tid = threadIdx.x, nthr = (int)blockDim.x, Wp = g.W * 64;
+  double *fk = dyn, *ela_old = dyn + K, *gla_old = dyn + 2 * K, *prs = dyn + 3 * K, *pss = dyn + 4 * K;
+  const ParOff o = par_off(g.L, Mp, K);
+  double* s1 = s1g + (size_t)l * Mp;
+  for (int k = tid; k < K; k += nthr) {
+    double f = 0.0;
+    for (int sl = 0; sl < NSLOT; ++sl) f += slotF[((size_t)l * NSLOT + sl) * K + k];
+    fk[k] = f;
+    ela_old[k] = par[o.p_shp + l * K + k] / par[o.p_rte + l * K + k];
+    gla_old[k] = par[o.G_la + l * K + k];
+    prs[k] = 0.0; pss[k] = 0.0;
+  }
+  for (int m = tid; m < Mp; m += nthr) s1[m] = 0.0;
+  __syncthreads();
+  const double gnu = par[o.sc + SC_G_NU];
+  const size_t hcs = (size_t)g.Y * Mp * K;
+  double* Hl = Hg + (size_t)l * hcs;
+  double* gth = par + o.G_th + (size_t)l * Mp;
+  for (size_t q = tid; q < hcs; q += nthr) {
+    const double hv = Hl[q];
+    if (hv == 0.0) continue;
+    const size_t it = q / K;
+    const int k = (int)(q - it * K), y = (int)(it / Mp), m = (int)(it - (size_t)y * Mp);
+    if (m >= M) continue;
+    const double w = g.mut ? w1_of(gth[m] * gla_old[k], gnu * (double)y) : 1.0;
+    atomicAdd(&s1[m], w * hv);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int m = tid; m < M; m += nthr) {
+    const size_t q = (size_t)l * Mp + m;
+    double rte = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double ak = fk[k];
+      for (int sl = 0; sl < NSLOT; ++sl) ak += slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];
+      rte += ela_old[k] * ak;
+    }
+    const double shp = par[o.a_th + q] + atomicAdd(&s1[m], 0.0);   // (a device-scope read of the sums the atomics left at the memory side)
+    rte = par[o.b_th + q] + rte;
+    par[o.g_shp + q] = shp; par[o.g_rte + q] = rte;
+    const double e = shp / rte, lg = digamma_pos(shp) - log(rte);
+    par[o.E_th + q] = e; par[o.l_th + q] = lg; par[o.G_th + q] = exp(lg);
+    for (int k = 0; k < K; ++k) {
+      double ak = fk[k];
+      for (int sl = 0; sl < NSLOT; ++sl) {
+        const size_t ix = (((size_t)l * NSLOT + sl) * Wp + m) * K + k;
+        ak += slotA[ix];
+        slotA[ix] = 0.0;   // (the slots are zero again for the next pass)
+      }
+      atomicAdd(&prs[k], e * ak);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // phi_shp's sums: H with the NEW G_theta and the old G_lambda (the cache refresh between the two updates, model.py:647);
+  // mutuality off: Y = 1 and the weight is 1 (model.py:680)
+  if ((do_phi && g.mut) || !g.mut) {
+    for (size_t q = tid; q < hcs; q += nthr) {
+      const double hv = Hl[q];
+      if (hv == 0.0) continue;
+      const size_t it = q / K;
+      const int k = (int)(q - it * K), y = (int)(it / Mp), m = (int)(it - (size_t)y * Mp);
+      if (m >= M) continue;
+      const double w = g.mut ? w1_of(gth[m] * gla_old[k], gnu * (double)y) : 1.0;
+      atomicAdd(&pss[k], w * hv);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += nthr) {
+    const int q = l * K + k;
+    const double rte = par[o.b_la + q] + prs[k];
+    if (g.mut && !do_phi) {
+      par[o.p_rte_pend + q] = rte;   // the PHI sub-step commits (k_fin_phi_gen)
+    } else {
+      const double shp = par[o.a_la + q] + pss[k];
+      par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
+      if (g.mut) par[o.p_rte_pend + q] = rte;
+      const double lg = digamma_pos(shp) - log(rte);
+      par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+    }
+  }
+  if (consume) {
+    for (size_t q = tid; q < hcs; q += nthr) Hl[q] = 0.0;
+    for (int q = tid; q < NSLOT * K; q += nthr) slotF[(size_t)l * NSLOT * K + q] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fin_phi_gen(double* par, const double* __restrict__ Hg, Geo g) {
+  extern __shared__ double dyn[];   // gla_old | pss, K each
+  const int K = g.K, Mp = g.Mp, M = g.M, l = blockIdx.x, tid = threadIdx.x, nthr = (int)blockDim.x;
+  double *gla_old = dyn, *pss = dyn + K;
+  const ParOff o = par_off(g.L, Mp, K);
+  for (int k = tid; k < K; k += nthr) { gla_old[k] = par[o.G_la + l * K + k]; pss[k] = 0.0; }
+  __syncthreads();
+  const double gnu = par[o.sc + SC_G_NU];
+  const size_t hcs = (size_t)g.Y * Mp * K;
+  const double* Hl = Hg + (size_t)l * hcs;
+  const double* gth = par + o.G_th + (size_t)l * Mp;   // new
+  for (size_t q = tid; q < hcs; q += nthr) {
+    const double hv = Hl[q];
+    if (hv == 0.0) continue;
+    const size_t it = q / K;
+    const int k = (int)(q - it * K), y = (int)(it / Mp), m = (int)(it - (size_t)y * Mp);
+    if (m >= M) continue;
+    atomicAdd(&pss[k], w1_of(gth[m] * gla_old[k], gnu * (double)y) * hv);
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += nthr) {
+    const int q = l * K + k;
+    const double shp = par[o.a_la + q] + pss[k], rte = par[o.p_rte_pend + q];
+    par[o.p_shp + q] = shp; par[o.p_rte + q] = rte;
+    const double lg = digamma_pos(shp) - log(rte);
+    par[o.E_la + q] = shp / rte; par[o.l_la + q] = lg; par[o.G_la + q] = exp(lg);
+  }
+}
+
+// Posterior samples (vmr_sample, k_sample in vimure_hip.hip) for K > KMAX: the trial counts live in LDS, one column per thread.
+__global__ __launch_bounds__(64) void k_sample_gen(const double* __restrict__ rho, uint8_t* __restrict__ out, size_t ties, int K, int n_trials,
+                                                   unsigned long long seed, const unsigned* __restrict__ perm, size_t T, size_t NS) {
+  extern __shared__ unsigned cnt_s[];   // [K][64]
+  unsigned* cnt = cnt_s + threadIdx.x;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < ties; q += (size_t)gridDim.x * blockDim.x) {
+    const double* r = rho + q * K;
+    size_t t = q;
+    if (perm) { const size_t l = q / T, pos = q - l * T; t = l * T + perm[l * NS * 64 + pos]; }
+    for (int k = 0; k < K; ++k) cnt[k * 64] = 0u;
+    for (int n = 0; n < n_trials; n += 2) {
+      unsigned c[4] = {(unsigned)t, (unsigned)((unsigned long long)t >> 32), (unsigned)(n >> 1), 0u};
+      philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+      for (int i = 0; i < 2; ++i) {
+        if (n + i < n_trials) {
+          const double u = ((double)(c[2 * i] >> 5) * 67108864.0 + (double)(c[2 * i + 1] >> 6)) * (1.0 / 9007199254740992.0);
+          int sel = 0;
+          double acc = r[0];
+          for (int k = 1; k < K; ++k) { if (u >= acc) sel = k; acc += r[k]; }
+          cnt[sel * 64] += 1u;
+        }
+      }
+    }
+    int best = 0;
+    for (int k = 1; k < K; ++k) if (cnt[k * 64] > cnt[best * 64]) best = k;
+    out[t] = (uint8_t)best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int gen_pass(vmr_ctx* h, int update, int elbo, int hist, int sum_a) {
+  const Geo& g = h->g;
+  const long long NS = ((long long)g.N * g.N + 63) / 64;
+  GenArgs a{h->E, h->EX, h->rs, h->ebase, h->perm, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par,
+            h->slotR, h->Hg, h->slotF, h->slotA, 1, update, elbo, hist, sum_a};
+  a.Gl = (int)std::max<long long>(1, std::min<long long>((NS + 3) / 4, std::max<long long>(1, (long long)h->ncu * 8 / g.L)));
+  const dim3 grid((unsigned)(g.L * a.Gl)), blk(256);
+  if (g.K <= 64) hipLaunchKernelGGL(k_sweep_gen<1>, grid, blk, 0, h->stream, a, g);
+  else if (g.K <= 128) hipLaunchKernelGGL(k_sweep_gen<2>, grid, blk, 0, h->stream, a, g);
+  else hipLaunchKernelGGL(k_sweep_gen<4>, grid, blk, 0, h->stream, a, g);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+static size_t gen_h_bytes(const Geo& g) { return (size_t)g.L * g.Y * g.Mp * g.K * 8; }
+
+int gen_hist(vmr_ctx* h) {
+  const Geo& g = h->g;
+  const int sum_a = h->n_partial > 0 ? 1 : 0;
+  HIPCHK(h, hipMemsetAsync(h->Hg, 0, gen_h_bytes(g), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
+  if (sum_a && !h->a_zero) HIPCHK(h, hipMemsetAsync(h->slotA, 0, (size_t)g.L * NSLOT * g.W * 64 * g.K * 8, h->stream));
+  {
+    Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
+    int rc = gen_pass(h, 0, 0, 1, sum_a);
+    if (rc) return rc;
+  }
+  h->h_valid = true; h->h_zero = false; h->h_reduced = true; h->f_valid = true; h->a_valid = true; h->a_zero = !sum_a;
+  return VMR_OK;
+}
+
+int gen_gamma(vmr_ctx* h, bool with_phi) {
+  const Geo& g = h->g;
+  if (!h->h_valid || !h->f_valid || !h->a_valid) { int rc = gen_hist(h); if (rc) return rc; }
+  {
+    Prof p(h, VMR_KERNEL_FINALIZE);
+    hipLaunchKernelGGL(k_fin_gamma_gen, dim3(g.L), dim3(256), (size_t)5 * g.K * 8, h->stream, h->par, h->Hg, h->slotA, h->slotF, h->gen_s1,
+                       with_phi ? 1 : 0, with_phi ? 1 : 0, g);
+  }
+  HIPCHK(h, hipGetLastError());
+  h->a_valid = false; h->a_zero = true;
+  if (with_phi) { h->h_valid = false; h->f_valid = false; h->h_zero = true; }
+  return VMR_OK;
+}
+
+int gen_phi(vmr_ctx* h) {
+  const Geo& g = h->g;
+  if (!g.mut) return VMR_OK;   // committed by k_fin_gamma_gen
+  if (!h->h_valid) { int rc = gen_hist(h); if (rc) return rc; }
+  {
+    Prof p(h, VMR_KERNEL_FINALIZE);
+    hipLaunchKernelGGL(k_fin_phi_gen, dim3(g.L), dim3(256), (size_t)2 * g.K * 8, h->stream, h->par, h->Hg, g);
+  }
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
+
+int gen_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu, gen_fin_rho_fn fin_rho) {
+  const Geo& g = h->g;
+  const int upd = mode != 2, sum_a = (upd && h->n_partial > 0) ? 1 : 0;
+  if (upd) {
+    if (!h->h_zero) {
+      HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
+      HIPCHK(h, hipMemsetAsync(h->Hg, 0, gen_h_bytes(g), h->stream));
+    }
+    h->h_zero = false;
+    if (sum_a && !h->a_zero) HIPCHK(h, hipMemsetAsync(h->slotA, 0, (size_t)g.L * NSLOT * g.W * 64 * g.K * 8, h->stream));
+    if (sum_a) h->a_zero = false;
+  }
+  {
+    Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
+    int rc = gen_pass(h, upd, mode != 0, upd, sum_a);
+    if (rc) return rc;
+  }
+  if (upd) { h->f_valid = true; h->h_valid = true; h->h_reduced = true; h->a_valid = true; }
+  if (mode == 2) return fin_rho(h, 0, 1, 1);
+  const bool nu = g.mut && (commit_nu || raw_nu);
+  if (mode != 0 || nu) return fin_rho(h, (commit_nu && g.mut) ? 1 : 0, mode != 0 ? 1 : 0, g.mut ? 0 : 1);
+  return VMR_OK;
+}
+
+int gen_sample(vmr_ctx* h, unsigned long long seed, int n_trials, uint8_t* out_dev) {
+  const Geo& g = h->g;
+  const size_t T_ = (size_t)g.N * g.N, ties = (size_t)g.L * T_, smem = (size_t)g.K * 64 * 4;
+  if (smem > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(k_sample_gen, dim3((unsigned)std::min<size_t>(4096, (ties + 63) / 64)), dim3(64), smem, h->stream, h->rho, out_dev, ties, g.K,
+                     n_trials, seed, h->perm, T_, (T_ + 63) / 64);
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}

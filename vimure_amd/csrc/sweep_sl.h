@@ -4,6 +4,8 @@
 // positions -- one wave, one tie per lane.  After the sort the ties of a step hold (almost) the same number of reports, so a
 // step is R_s full rounds of 64 slots and nothing else:
 //     E[ebase[l] + rs[l][s] + r * 64 + lane]   the r-th report of the tie at position s * 64 + lane (0 = none)
+//     (wide entries, Geo::wide -- counts beyond 2047 or more than 2^20 table rows; the general kernels of sweep_gen.hip only:
+//      E[slot] = y * Mp + m in 32 bits, EX[slot] = x << 1 | R[l,i,j,m])
 //     entry   bits 0..19  y * Mp + m  (mirror count y = X[l,j,i,m], 0 when mutuality is off; reporter m): the row of the
 //                         per-(y, m) tables F and H        bit 20  R[l,i,j,m]        bits 21..31  the count x (<= 2047)
 //     rs[l][s] (u32, NS + 1 per layer)   first slot of step s;  R_s = (rs[s+1] - rs[s]) / 64, non-increasing in s
@@ -104,8 +106,9 @@ sl_launch_batch_fn vmr_sl_batch_launcher(int K);
 // Builds perm, rs, E (and ebase, n_slots) from tie-major entries.  rp [L][T+1]: per-tie report counts (overwritten by their
 // exclusive scan); nl[l]: reports of layer l; etmp_all: every layer's entries tie-major (layer l at offset sum nl[<l]) or null,
 // then fill(l, rp_l scanned, etmp) writes layer l's.
-typedef std::function<void(int l, const unsigned* rpl, unsigned* etmp)> SlFill;
-int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, const SlFill* fill);
+// Wide entries (Geo::wide): every entry is two words -- etmp2 / etmp2_all hold the second ones -- and h->EX receives them.
+typedef std::function<void(int l, const unsigned* rpl, unsigned* etmp, unsigned* etmp2)> SlFill;
+int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long long>& nl, unsigned* etmp_all, unsigned* etmp2_all, const SlFill* fill);
 // out[l][pos] = in[l][perm[l][pos]] for the per-tie arrays the sweeps read by position
 int sl_permute_u8(vmr_ctx* h, const uint8_t* in, uint8_t* out);
 int sl_permute_u32(vmr_ctx* h, const unsigned* in, unsigned* out);

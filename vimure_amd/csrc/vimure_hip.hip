@@ -17,6 +17,7 @@
 //                  (digamma/log/exp), ELBO assembly -- no host round trip inside a sweep.
 #include "vmr_internal.h"
 #include "sweep_sl.h"
+#include "sweep_gen.h"
 
 thread_local std::string g_create_err;
 
@@ -1034,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned* a, const unsigned* _
 // per-tie counts: tie t's entries start at rpl[t], reporters ascending.
 template <bool MUT>
 __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl, const uint64_t* __restrict__ Rl,
-                                                 const unsigned* __restrict__ rpl, unsigned* __restrict__ El,
+                                                 const unsigned* __restrict__ rpl, unsigned* __restrict__ El, unsigned* __restrict__ El2 /*wide entries: the second words*/,
                                                  unsigned* __restrict__ Qtl, Geo g) {
   const int gl = threadIdx.x & 15;
   const size_t T = (size_t)g.N * g.N, Tr = (T + 15) / 16 * 16;
@@ -1079,7 +1080,8 @@ __global__ __launch_bounds__(256) void k_sp_fill(const uint8_t* __restrict__ Xl,
             y = (ys[u] >> sh) & 0xffu;
             if ((rmr[m >> 6] >> (m & 63)) & 1ull) q += x;   // R[mirror,m] X[this,m]
           }
-          El[w++] = (y * (unsigned)g.Mp + (unsigned)m) | (inr << 20) | (x << 21);   // (sweep_sl.h)
+          if (El2) { El[w] = y * (unsigned)g.Mp + (unsigned)m; El2[w] = (x << 1) | inr; ++w; }
+          else El[w++] = (y * (unsigned)g.Mp + (unsigned)m) | (inr << 20) | (x << 21);   // (sweep_sl.h)
         }
       }
       pos += tot;
@@ -1550,18 +1552,24 @@ __device__ __forceinline__ void fin_rho_body(double* par, double* Hg, const doub
   if (!skip_nu && (g.mut || fold)) {   // threads take (y, m) items of H; fold: the NH copies are summed into copy 0 on the way
     const double gnu = sc[SC_G_NU];
     const size_t hcs = (size_t)g.Y * g.Mp * g.K;
-    double* Hl = Hg + (size_t)l * NH * hcs;
-    const int items = g.Y * g.Mp, i0 = (int)((long long)gs * items / FR_G), i1 = (int)((long long)(gs + 1) * items / FR_G);
-    for (int it = i0 + (int)threadIdx.x; it < i1; it += TPB) {
-      const int y = it / g.Mp, m = it - y * g.Mp;
+    double* Hl = Hg + (size_t)l * (g.gen ? 1 : NH) * hcs;   // (the general kernels keep one copy of H, every category in it)
+    const long long items = (long long)g.Y * g.Mp, i0 = (long long)gs * items / FR_G, i1 = (long long)(gs + 1) * items / FR_G;
+    for (long long it = i0 + (int)threadIdx.x; it < i1; it += TPB) {
+      const int y = (int)(it / g.Mp), m = (int)(it - (long long)y * g.Mp);
       if (m >= g.M || (y == 0 && !fold)) continue;
       const double gth = par[o.G_th + (size_t)l * g.Mp + m], z2 = gnu * (double)y;
-      double hk[KMAX];
-      if (fold) h_fold_item(Hl, hcs, (size_t)it, g.K, Cg ? Cg + (size_t)l * items : nullptr, hk);
-      else for (int k = 0; k < g.K; ++k) hk[k] = Hl[(size_t)it * g.K + k];
-      for (int k = 0; k < g.K; ++k) {
-        const double z1 = gth * par[o.G_la + l * g.K + k];
-        if (g.mut && y > 0) a0 += (z2 / (z1 + z2)) * hk[k];
+      if (fold) {   // (specialised kernels only: K <= KMAX)
+        double hk[KMAX];
+        h_fold_item(Hl, hcs, (size_t)it, g.K, Cg ? Cg + (size_t)l * items : nullptr, hk);
+        for (int k = 0; k < g.K; ++k) {
+          const double z1 = gth * par[o.G_la + l * g.K + k];
+          if (g.mut && y > 0) a0 += (z2 / (z1 + z2)) * hk[k];
+        }
+      } else if (g.mut && y > 0) {
+        for (int k = 0; k < g.K; ++k) {
+          const double hv = Hl[(size_t)it * g.K + k];
+          if (hv != 0.0) a0 += (z2 / (gth * par[o.G_la + l * g.K + k] + z2)) * hv;
+        }
       }
     }
   }
@@ -1677,16 +1685,6 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ rho,
 // (seed, tie, trial) only -- reproducible, and the same for every data layout -- not on NumPy's PCG64 stream, which a GPU cannot
 // follow (the host class keeps that exact mode; this one is checked by distribution).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
 __global__ __launch_bounds__(256) void k_sample(const double* __restrict__ rho, uint8_t* __restrict__ out, size_t ties, int K, int n_trials,
                                                 unsigned long long seed, const unsigned* __restrict__ perm, size_t T, size_t NS) {
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < ties; q += (size_t)gridDim.x * blockDim.x) {
@@ -1789,7 +1787,7 @@ static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
 // k_fin_rho: nu and/or the ELBO; folds the NH copies of H into copy 0 on its way when they are not folded yet
 static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo, int skip_nu = 0) {
   const Geo& g = h->g;
-  const int fold = (!skip_nu && h->h_valid && !h->h_reduced) ? 1 : 0;
+  const int fold = (!skip_nu && h->h_valid && !h->h_reduced && !g.gen) ? 1 : 0;
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     hipLaunchKernelGGL(k_fin_rho, dim3(g.L * FR_G), dim3(TPB), 0, h->stream, h->par, h->Hg, h->Cg, h->slotR, h->elbo_dev,
@@ -1847,6 +1845,7 @@ static int det_fold(vmr_ctx* h) {
 // nu: -1 = the pass leaves nu alone; 0 = it leaves the raw sum in elbo_dev[1]; 1 = it also commits nu (sorted lists, see SlArgs::nu_acc)
 static int launch_hist(vmr_ctx* h, int nu = -1) {
   const Geo& g = h->g;
+  if (g.gen) return gen_hist(h);
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
     HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));   // (the pass sums rho over all-ones mask rows)
@@ -1883,6 +1882,7 @@ static int launch_hist(vmr_ctx* h, int nu = -1) {
 
 static int launch_gamma(vmr_ctx* h, bool with_phi) {
   const Geo& g = h->g;
+  if (g.gen) return gen_gamma(h, with_phi);
   if (h->sparse && !h->h_valid) {   // report lists: the statistics pass also sums rho over the all-ones mask rows (slotF)
     int rc = launch_hist(h);
     if (rc) return rc;
@@ -1949,6 +1949,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
 
 static int launch_phi(vmr_ctx* h) {
   const Geo& g = h->g;
+  if (g.gen) return gen_phi(h);
   if (!g.mut) return VMR_OK;   // committed by k_fin_gamma
   if (!h->h_valid) { int rc = launch_hist(h); if (rc) return rc; }
   { int rc = ensure_h_folded(h); if (rc) return rc; }
@@ -1964,6 +1965,7 @@ static int launch_phi(vmr_ctx* h) {
 // raw_nu: leave the raw nu sum in elbo_dev[1] although nu is not committed (vmr_sweep_local)
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false) {
   const Geo& g = h->g;
+  if (g.gen) return gen_rho(h, mode, commit_nu, raw_nu, [](vmr_ctx* hh, int do_nu, int do_elbo, int skip_nu) { return launch_fin_rho(hh, do_nu, do_elbo, skip_nu); });
   RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
@@ -2066,7 +2068,7 @@ const char* vmr_last_error(vmr_handle h) { return h ? h->err.c_str() : g_create_
 // context, geometry, streams and the small per-dataset arrays
 static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, int N, int M, int K, int mutuality, double eps) {
   if (L < 1 || N < 1 || M < 1) return fail(nullptr, VMR_EINVAL, "L, N, M must be positive");
-  if (K < 2 || K > KMAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 8]");
+  if (K < 2 || K > KGEN_MAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 256]");
   int ndev = 0;
   CK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(nullptr, VMR_EINVAL, "no such HIP device");
@@ -2077,6 +2079,7 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
   h->device = device;
   Geo& g = h->g;
   g.L = L; g.N = N; g.M = M; g.K = K; g.mut = mutuality ? 1 : 0; g.eps = eps;
+  g.gen = K > KMAX ? 1 : 0; g.wide = 0;   // (wide entries: decided once the largest count is known)
   std::string err;
   if (choose_geo(g, prop->multiProcessorCount, err) != VMR_OK) return fail(nullptr, VMR_EINVAL, err.c_str());
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
@@ -2253,11 +2256,37 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
   Geo& g = h->g;
   const int L = g.L, K = g.K;
   g.ml = (h->sparse && h->rq) ? 1 : 0;
-  if (g.ml && h->rm_maxrow <= 2 && !getenv("VMR_NO_RM2")) {   // (the self-reporter mask of survey data: lists of two)
+  if (g.ml && !g.gen && h->rm_maxrow <= 2 && !getenv("VMR_NO_RM2")) {   // (the self-reporter mask of survey data: lists of two)
     const size_t T_ = (size_t)g.N * g.N, NS_ = (T_ + 63) / 64, n_ = (size_t)L * NS_ * 64;
     CK(hipMalloc(&h->rm2, n_ * 4));
     hipLaunchKernelGGL(k_rm2, dim3((unsigned)std::min<size_t>(4096, (n_ + 255) / 256)), dim3(256), 0, h->stream, h->perm, h->rq, h->Rm, h->rbase, h->rm2, T_, NS_, L);
     CK(hipGetLastError());
+  }
+  if (g.gen) {
+    // the general kernels: one copy of H with every category, nothing in LDS, no constants C (sweep_gen.h)
+    if (g.det) return fail(nullptr, VMR_EINVAL, "VMR_DETERMINISTIC=1 needs the specialised kernels: K <= 8, counts <= 2047, (largest count + 1) * M <= 2^20");
+    g.ml = 0; g.hc = 0; g.yt = 0; g.two_pass = 0;
+    if (h->rm2) { CK(hipFree(h->rm2)); h->rm2 = nullptr; }
+    const double hb = (double)L * g.Y * g.Mp * K * 8.0;
+    size_t fr = 0, tot = 0;
+    CK(hipMemGetInfo(&fr, &tot));
+    if (hb > 0.5 * (double)fr) {
+      char msg[256];
+      snprintf(msg, sizeof msg, "the statistics table H[L][max count + 1][M][K] would take %.1f GB (largest count %d, M = %d, K = %d): more than half "
+               "of the device memory left", hb / 1e9, g.Y - 1, g.M, K);
+      return fail(nullptr, VMR_EINVAL, msg);
+    }
+    CK(hipMalloc(&h->Hg, (size_t)hb));
+    CK(hipMemsetAsync(h->Hg, 0, (size_t)hb, h->stream));
+    CK(hipMalloc(&h->gen_s1, (size_t)L * g.Mp * 8));
+    CK(hipMalloc(&h->elbo_dev, 8 * 8));
+    CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
+    CK(hipMalloc(&h->nu_acc, (size_t)(3 + L) * 8));
+    CK(hipMemsetAsync(h->nu_acc, 0, (size_t)(3 + L) * 8, h->stream));
+    CK(hipMalloc(&h->lutg, (size_t)L * g.W * 256 * 8));
+    CK(hipMemsetAsync(h->lutg, 0, (size_t)L * g.W * 256 * 8, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    return VMR_OK;
   }
   // LDS levels (mirror counts 0..) of the statistics H and, for report lists, of the factor table F.
   g.hc = g.Y < HC_MAX ? g.Y : HC_MAX;
@@ -2424,8 +2453,14 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
   const char* fmt = getenv("VMR_FORMAT");   // "dense", "sparse" or unset/"auto"
   const bool force_dense = fmt && !strcmp(fmt, "dense"), force_sparse = fmt && !strcmp(fmt, "sparse");
   // 13-bit reporter field; the sorted lists hold counts <= 2047 and (max count + 1) * Mp <= 2^20 table rows, the step layout counts <= 63
-  const bool can_list = g.Mp <= 8192 && xm <= SL_XMAX && (size_t)(xm + 1) * g.Mp <= SL_YM_ROWS;
+  const bool packed_ok = g.Mp <= 8192 && xm <= SL_XMAX && (size_t)(xm + 1) * g.Mp <= SL_YM_ROWS;
+  // beyond KMAX categories there is no dense-tile kernel: the general kernels run on report lists, with wide entries where the
+  // packed ones cannot hold the tensor (a uint8 tensor always fits: 256 levels x Mp rows < 2^32)
+  const bool need_lists = g.K > KMAX;
+  if (need_lists && force_dense) return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=dense: the dense tile kernels hold at most 8 categories");
+  const bool can_list = packed_ok || need_lists || force_sparse;   // (VMR_FORMAT=sparse: wide entries for what the packed ones cannot hold)
   if (!force_dense && can_list) {
+    g.wide = packed_ok ? 0 : 1;
     unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
     CK(hipMalloc(&rp, (size_t)L * (T + 1) * 4));
     unsigned long long* nnz_dev = nullptr;
@@ -2444,21 +2479,24 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
     h->nnz = 0;
     for (int l = 0; l < L; ++l) { h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
     const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
-    h->sparse = fits && (force_sparse || sparse_bytes <= 0.5 * dense_bytes);
+    if (need_lists && !fits) { (void)hipFree(rp); return fail(nullptr, VMR_EINVAL, "more than 2^32 reports in one layer"); }
+    h->sparse = fits && (force_sparse || need_lists || sparse_bytes <= 0.5 * dense_bytes);
+    if (!h->sparse) g.wide = 0;
+    g.gen = (h->sparse && (need_lists || g.wide)) ? 1 : 0;
     if (h->sparse) {
       CK(hipMalloc(&h->Qt, rows * 4));
       CK(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-      auto fill_layer = [&](int l, const unsigned* rpl, unsigned* etmp) {
+      auto fill_layer = [&](int l, const unsigned* rpl, unsigned* etmp, unsigned* etmp2) {
         if (g.mut)
           hipLaunchKernelGGL(k_sp_fill<true>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, etmp2, h->Qt + (size_t)l * T, g);
         else
           hipLaunchKernelGGL(k_sp_fill<false>, dim3(cgrid), dim3(256), 0, h->stream, h->X + (size_t)l * T * g.Mp,
-                             h->Rb + (size_t)l * T * g.W, rpl, etmp, h->Qt + (size_t)l * T, g);
+                             h->Rb + (size_t)l * T * g.W, rpl, etmp, etmp2, h->Qt + (size_t)l * T, g);
       };
       {
         const SlFill ff = fill_layer;
-        rc = sl_place_entries(h, rp, nl, nullptr, &ff);
+        rc = sl_place_entries(h, rp, nl, nullptr, nullptr, &ff);
         if (!rc) rc = sl_finish(h);
       }
       if (!rc) rc = mask_lists_from_words(h);
@@ -2467,7 +2505,7 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
     CK(hipFree(rp));
     if (rc) return rc;
   } else if (force_sparse) {
-    return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192 and counts <= 63");
+    return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=sparse needs M <= 8192, counts <= 2047 and (largest count + 1) * M <= 2^20");
   }
   return create_tail(h, prop);
 }
@@ -2477,7 +2515,7 @@ extern "C" int vmr_create(vmr_handle* out, int device, int L, int N, int M, int 
   if (!out) return fail(nullptr, VMR_EINVAL, "out is NULL");
   *out = nullptr;
   if (L < 1 || N < 1 || M < 1) return fail(nullptr, VMR_EINVAL, "L, N, M must be positive");
-  if (K < 2 || K > KMAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 8]");
+  if (K < 2 || K > KGEN_MAX) return fail(nullptr, VMR_EINVAL, "K must be in [2, 256]");
   if (!X) return fail(nullptr, VMR_EINVAL, "X is NULL");
   vmr_ctx* h = nullptr;
   hipDeviceProp_t prop;
@@ -2546,14 +2584,14 @@ __global__ void k_coo_class(const unsigned* __restrict__ cx, const unsigned* __r
 template <bool MUT>
 __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const unsigned* __restrict__ vx, long long nx,
                               const unsigned long long* __restrict__ kr, long long nr /* < 0: all ones */, int N, int Mp,
-                              unsigned* __restrict__ etmp, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad) {
+                              unsigned* __restrict__ etmp, unsigned* __restrict__ etmp2, unsigned* __restrict__ Qt, unsigned long long* sumx, unsigned* xmax, int* bad) {
   unsigned long long s = 0;
   unsigned mx = 0;
   const unsigned long long T = (unsigned long long)N * N;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (long long)gridDim.x * blockDim.x) {
     const unsigned long long key = kx[e], tie = key >> 13, l = tie / T, t = tie - l * T, i = t / N, j = t - i * N;
     const unsigned m = (unsigned)(key & 0x1fffu), x = vx[e];
-    if (x == 0u || x > SL_XMAX) { atomicOr(bad, 4); continue; }
+    if (x == 0u || x > 0x7fffffffu) { atomicOr(bad, 4); continue; }   // (int32 values: zero or negative)
     s += x; mx = max(mx, x);
     const unsigned long long tm = l * T + j * N + i;
     unsigned y = 0;
@@ -2563,10 +2601,20 @@ __global__ void k_coo_entries(const unsigned long long* __restrict__ kx, const u
       if (nr < 0 || coo_find(kr, nr, COO_KEY(tm, m)) >= 0) atomicAdd(&Qt[tm], x);   // R[mirror, m] X[this, m]
     }
     const unsigned inr = (nr < 0 || coo_find(kr, nr, key) >= 0) ? 1u : 0u;
-    etmp[e] = (y * (unsigned)Mp + m) | (inr << 20) | (x << 21);   // (sweep_sl.h)
+    // two words per entry (sweep_sl.h, wide entries); k_coo_pack folds them into one where the packed format holds the tensor
+    const unsigned long long row = (unsigned long long)y * (unsigned)Mp + m;
+    if (row > 0xffffffffull) atomicOr(bad, 8);
+    etmp[e] = (unsigned)row;
+    etmp2[e] = (x << 1) | inr;
   }
   if (s) atomicAdd(sumx, s);
   if (mx) atomicMax(xmax, mx);
+}
+__global__ void k_coo_pack(unsigned* __restrict__ etmp, const unsigned* __restrict__ etmp2, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const unsigned w = etmp2[e];
+    etmp[e] = etmp[e] | ((w & 1u) << 20) | ((w >> 1) << 21);
+  }
 }
 // first sorted key of every layer (starts[L] = n)
 __global__ void k_coo_layer_starts(const unsigned long long* __restrict__ k, long long n, unsigned long long T, int L, unsigned long long* starts) {
@@ -2665,8 +2713,8 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   unsigned* vx = nullptr;
   int rc = coo_sorted(h, nx, xl, xi, xj, xm, xv, on_device, &kx, &vx, bad_dev);
   if (!rc && nr >= 0) rc = coo_sorted(h, nr, rl, ri, rj, rm, nullptr, on_device, &kr, nullptr, bad_dev);
-  unsigned *cx = nullptr, *cr = nullptr, *etmp = nullptr, *maxrow_dev = nullptr;
-  auto cleanup = [&]() { void* p[] = {bad_dev, kx, kr, vx, cx, cr, etmp, maxrow_dev}; for (void* q : p) if (q) (void)hipFree(q); };
+  unsigned *cx = nullptr, *cr = nullptr, *etmp = nullptr, *etmp2 = nullptr, *maxrow_dev = nullptr;
+  auto cleanup = [&]() { void* p[] = {bad_dev, kx, kr, vx, cx, cr, etmp, etmp2, maxrow_dev}; for (void* q : p) if (q) (void)hipFree(q); };
   if (rc) { cleanup(); return rc; }
   {   // subscripts outside the tensor must not reach the kernels below (their keys index the per-tie arrays)
     int bad0 = 0;
@@ -2689,10 +2737,11 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
   hipLaunchKernelGGL(k_coo_class, dim3((unsigned)std::min<size_t>(4096, (rows + 255) / 256)), dim3(256), 0, h->stream, cx, cr, T, L, M,
                      h->cov, h->rcls, h->npartial, maxrow_dev);
   CKC(hipMalloc(&etmp, ((size_t)nx + 64) * 4));
+  CKC(hipMalloc(&etmp2, ((size_t)nx + 64) * 4));
   CKC(hipMalloc(&h->Qt, rows * 4));
   CKC(hipMemsetAsync(h->Qt, 0, rows * 4, h->stream));
-  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
-  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, h->Qt, h->sumx, h->xmax, bad_dev);
+  if (g.mut) hipLaunchKernelGGL(k_coo_entries<true>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, etmp2, h->Qt, h->sumx, h->xmax, bad_dev);
+  else hipLaunchKernelGGL(k_coo_entries<false>, dim3(gx), dim3(256), 0, h->stream, kx, vx, nx, kr, nr, N, g.Mp, etmp, etmp2, h->Qt, h->sumx, h->xmax, bad_dev);
   CKC(hipGetLastError());
   CKC(hipStreamSynchronize(h->stream));
   int bad = 0;
@@ -2704,7 +2753,8 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     cleanup();
     return fail(nullptr, VMR_EINVAL, (bad & 1) ? "a subscript lies outside (L, N, N, M)"
                                    : (bad & 2) ? "duplicate (l, i, j, m) subscripts"
-                                               : "counts must lie in [1, 2047] for the report lists");
+                                   : (bad & 4) ? "counts must be positive (and below 2^31)"
+                                               : "(largest count + 1) * M exceeds 2^32 table rows");
   }
   unsigned xmv = 0;
   if ((rc = create_state(h, &xmv))) { cleanup(); return rc; }
@@ -2723,11 +2773,19 @@ static int create_coo(vmr_ctx* h, const hipDeviceProp_t& prop, long long nx, con
     CKC(e1);
     for (int l = 0; l < L; ++l) nl[l] = st[l + 1] - st[l];
   }
-  if ((size_t)(xmv + 1) * g.Mp > SL_YM_ROWS) {
+  // packed entries (11-bit counts, 2^20 table rows) where they hold the tensor, two words per entry otherwise; the general
+  // kernels take over beyond KMAX categories or with wide entries (sweep_gen.h)
+  g.wide = (xmv <= SL_XMAX && (size_t)(xmv + 1) * g.Mp <= SL_YM_ROWS) ? 0 : 1;
+  g.gen = (K > KMAX || g.wide) ? 1 : 0;
+  if ((unsigned long long)xmv * (unsigned long long)M > 0xffffffffull) {
     cleanup();
-    return fail(nullptr, VMR_EINVAL, "(largest count + 1) * M exceeds the 2^20 table rows of the report lists");
+    return fail(nullptr, VMR_EINVAL, "largest count * M exceeds 2^32 (the per-tie mirror sums are 32-bit)");
   }
-  rc = sl_place_entries(h, cx, nl, etmp, nullptr);
+  if (!g.wide) {
+    hipLaunchKernelGGL(k_coo_pack, dim3(gx), dim3(256), 0, h->stream, etmp, etmp2, (long long)nx);
+    CKC(hipGetLastError());
+  }
+  rc = sl_place_entries(h, cx, nl, etmp, g.wide ? etmp2 : nullptr, nullptr);
   if (!rc) rc = sl_finish(h);
   if (rc) { cleanup(); return rc; }
   // the mask: all ones needs nothing; partial rows become mask lists when they are short, bit-packed words otherwise
@@ -2791,7 +2849,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3030,7 +3088,7 @@ static bool batch_steady(const vmr_ctx* h) {
 }
 static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
   // (a sweep of such a handle is k_fin_gamma + the pass, + k_fin_rho with an ELBO: the pass sums rho over the mask itself)
-  return h->sparse && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
+  return h->sparse && !h->g.gen && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
          h->g.K == h0->g.K && h->g.mut == h0->g.mut && (h->all_full != 0) == (h0->all_full != 0);
 }
 namespace {
@@ -3466,8 +3524,9 @@ int vmr_sample(vmr_handle h, uint64_t seed, int n_trials, uint8_t* out, int out_
   const size_t T_ = (size_t)g.N * g.N, ties = (size_t)g.L * T_;
   uint8_t* dst = out;
   if (!out_on_device) HIPCHK(h, hipMalloc(&dst, ties));
-  hipLaunchKernelGGL(k_sample, dim3((unsigned)std::min<size_t>(4096, (ties + 255) / 256)), dim3(256), 0, h->stream, h->rho, dst, ties, g.K,
-                     n_trials, (unsigned long long)seed, h->perm, T_, (T_ + 63) / 64);
+  if (g.K > KMAX) { const int rcg = gen_sample(h, (unsigned long long)seed, n_trials, dst); if (rcg) { if (!out_on_device) (void)hipFree(dst); return rcg; } }
+  else hipLaunchKernelGGL(k_sample, dim3((unsigned)std::min<size_t>(4096, (ties + 255) / 256)), dim3(256), 0, h->stream, h->rho, dst, ties, g.K,
+                          n_trials, (unsigned long long)seed, h->perm, T_, (T_ + 63) / 64);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, dst, ties, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

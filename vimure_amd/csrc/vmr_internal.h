@@ -29,7 +29,8 @@
 #ifndef VMR_NR_STEPS
 #define VMR_NR_STEPS 1   // v_rcp_f64 is good to 4.6e-8; one step gives 2e-15, two are exact (tools/rcp_accuracy.hip)
 #endif
-#define KMAX 8
+#define KMAX 8        // categories the specialised kernels are compiled for (one sweep object per K, per-K register budgets)
+#define KGEN_MAX 256  // ... and the general kernels (sweep_gen.hip: a category per lane) take: K = max(X) + 1 is the reference's default (model.py:179-197)
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -62,6 +63,9 @@ struct Geo {
   int det;      // VMR_DETERMINISTIC=1: bit-reproducible sweeps (one wave per workgroup, fixed step shares, integer cross-workgroup sums)
   int det_sh;   // ... whose fixed point for count-weighted sums (H, the nu share) is 2^-det_sh: sum x of the dataset < 2^(62 - det_sh)
   int det_shr;  // ... and 2^-det_shr for the ELBO partials (bounded by 64 (sum x + ties K))
+  int gen;      // the general kernels (sweep_gen.hip): K > KMAX, or entries too wide for the packed format.  H is then ONE copy
+                // [L][Y][Mp][K] holding every category (no constant C, no deficits), nu and the mask sums go through k_fin_rho / the pass
+  int wide;     // entries in two words (vmr_ctx::EX): counts beyond 2047 or (max count + 1) * Mp beyond 2^20 table rows
 };
 // fixed point of the deterministic mode: count-weighted sums 2^-g.det_sh; ELBO partials 2^-g.det_shr; sums of rho over ties (< 2^31 ties) 2^-30
 #define DET_SH_A 30
@@ -85,6 +89,8 @@ struct vmr_ctx {
   // report lists (sparse format, see k_rho_sp); X is freed once they exist
   int sparse = 0;
   unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
+  unsigned* EX = nullptr;      // wide entries (Geo::wide): E holds the table row y * Mp + m in 32 bits, EX the count << 1 | R[l,i,j,m], same slots
+  double* gen_s1 = nullptr;    // [L][Mp] scratch of k_fin_gamma_gen
   unsigned* rs = nullptr;      // [L][N*N/64+1] first entry of every 64-tie step, relative to ebase[l]
   double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
   int sp_tpb = 256;            // threads per workgroup of the report-list passes that update rho or reduce the ELBO
@@ -387,6 +393,17 @@ __device__ __forceinline__ void store_k(double* __restrict__ p, const double (&v
   }
 }
 
+// Philox4x32-10 (Salmon et al. 2011): the counter-based generator of the device sampler and the device generator
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
 static inline int fail(vmr_handle h, int code, const char* msg) {
   if (h) h->err = msg; else g_create_err = msg;
   return code;

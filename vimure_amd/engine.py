@@ -56,6 +56,8 @@ class CaviEngine:
             xp, rp = X.data_ptr(), (R.data_ptr() if R is not None else None)
             shape = tuple(X.shape)
         else:
+            if getattr(X, "dtype", np.uint8) != np.uint8 and np.size(X) and (np.min(X) < 0 or np.max(X) > 255):
+                raise ValueError("dense X is a uint8 tensor (counts in [0, 255]); larger counts go through CaviEngine.from_coo")
             X = np.ascontiguousarray(X, dtype=np.uint8)
             if R is not None:
                 R = np.ascontiguousarray(R, dtype=np.uint8)
@@ -81,7 +83,7 @@ class CaviEngine:
     def from_coo(cls, subs, vals, shape, R=None, K=2, mutuality=True, eps=1e-12, device=None):
         """Dataset from coordinate lists -- the reference's own containers (`X.subs`, `X.vals`, `R.subs`; reference
         model.py:136-171) -- without a dense [L,N,N,M] tensor on the host or the device (vmr_create_coo).
-        subs: 4 index arrays (l, i, j, m); vals: counts in [1, 2047]; R: None (every reporter may report on every tie) or 4
+        subs: 4 index arrays (l, i, j, m); vals: counts in [1, 2^31); R: None (every reporter may report on every tie) or 4
         index arrays of the mask's non-zeros; NumPy arrays or torch GPU tensors (int32 / int64)."""
         self = cls.__new__(cls)
         self._h = C.c_void_p()

@@ -19,7 +19,7 @@ from scipy.stats import poisson
 
 from ._log import setup_logging
 from .engine import CaviEngine, host_buffer
-from .tensor import SparseTensor, is_sparse_like, to_dense_u8
+from .tensor import SparseTensor, engine_data, is_sparse_like, to_dense_u8
 
 try:  # the reference is an sklearn estimator (model.py:28); keep that surface when sklearn is there
     from sklearn.base import BaseEstimator, TransformerMixin
@@ -80,20 +80,31 @@ class VimureModel(TransformerMixin, BaseEstimator):
         dev_tensor = _is_torch(X)
         # a coordinate container (the reference's sptensor surface: subs / vals / shape) goes to the device as it is
         # (vmr_create_coo) when the report lists can hold it; no dense [L,N,N,M] array is built then
-        coo = (not dev_tensor and is_sparse_like(X) and not self.undirected and extra.get("engine") is None
-               and int(X.shape[3]) <= 8192 and (len(X.vals) == 0 or (np.min(X.vals) >= 1 and np.max(X.vals) <= 2047)))
-        if dev_tensor or coo or (extra.get("engine") is not None and is_sparse_like(X)):
+        # (and so does a dense array whose counts pass 255: the engine takes any count the reference's int64 holds, below 2^31)
+        coo = False
+        if dev_tensor or (extra.get("engine") is not None and is_sparse_like(X)):
             Xd = X   # (with `engine` the data is on the device already: only the shape is needed)
             shape = tuple(int(s) for s in X.shape)
         else:
-            Xd = to_dense_u8(X, "X")
-            shape = Xd.shape
+            Xd = engine_data(X, "X") if extra.get("engine") is None else to_dense_u8(X, "X")
+            if self.undirected and is_sparse_like(Xd) and (len(Xd.vals) == 0 or np.max(Xd.vals) <= 255):
+                Xd = to_dense_u8(Xd, "X")   # (the symmetry check below reads the array)
+            coo = is_sparse_like(Xd)
+            shape = tuple(int(s) for s in Xd.shape)
         if len(shape) != 4 or shape[1] != shape[2]:
             raise ValueError("X must have shape (L, N, N, M)")
         self.L, self.N, self.M = shape[0], shape[1], shape[3]
 
         if self.undirected:
-            sym = bool((Xd == Xd.transpose(1, 2)).all()) if dev_tensor else np.array_equal(Xd, Xd.transpose(0, 2, 1, 3))
+            if coo:   # counts beyond a byte: compare the coordinate lists with their (i, j)-swapped selves
+                sl, si, sj, sm = (np.asarray(a, dtype=np.int64) for a in Xd.subs)
+                v = np.asarray(Xd.vals)
+                ka = np.ravel_multi_index((sl, si, sj, sm), shape)
+                kb = np.ravel_multi_index((sl, sj, si, sm), shape)
+                oa, ob = np.argsort(ka), np.argsort(kb)
+                sym = bool(np.array_equal(ka[oa], kb[ob]) and np.array_equal(v[oa], v[ob]))
+            else:
+                sym = bool((Xd == Xd.transpose(1, 2)).all()) if dev_tensor else np.array_equal(Xd, Xd.transpose(0, 2, 1, 3))
             if not sym:
                 msg = "If undirected is True, the given network has to be symmetric wrt l and m!"
                 self.logger.error(msg)

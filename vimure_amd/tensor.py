@@ -54,6 +54,32 @@ def is_sparse_like(X):
     return hasattr(X, "subs") and hasattr(X, "vals") and hasattr(X, "shape")
 
 
+COUNT_MAX = 2 ** 31 - 1   # counts travel as int32 coordinate values (vmr_create_coo); the reference holds int64 (utils.py:241-242)
+M_COO_MAX = 8192          # 13-bit reporter field of the coordinate keys
+
+
+def engine_data(X, what="X"):
+    """The form a count tensor reaches the engine in: a coordinate container (-> vmr_create_coo: any count, M <= 8192) or a dense
+    uint8 array (-> vmr_create: counts <= 255, any M).  A dense array with larger counts becomes its coordinate lists."""
+    if is_sparse_like(X):
+        vals = np.asarray(X.vals)
+        if len(vals) and (vals.min() < 0 or vals.max() > COUNT_MAX):
+            raise ValueError(f"{what} entries must be integers in [0, 2^31)")
+        if int(X.shape[3]) <= M_COO_MAX and (len(vals) == 0 or vals.min() >= 1):
+            return X
+        if len(vals) and vals.max() > 255:
+            raise ValueError(f"{what}: counts above 255 need the coordinate-list layout, which holds M <= {M_COO_MAX} reporters")
+        return to_dense_u8(X, what)
+    A = np.asarray(X)
+    if A.size and A.dtype != np.uint8 and A.max() > 255:
+        if A.min() < 0 or A.max() > COUNT_MAX:
+            raise ValueError(f"{what} entries must be integers in [0, 2^31)")
+        if A.ndim != 4 or A.shape[3] > M_COO_MAX:
+            raise ValueError(f"{what}: counts above 255 need the coordinate-list layout, which holds M <= {M_COO_MAX} reporters")
+        return SparseTensor.fromarray(A.astype(np.int64) if A.dtype.kind == "f" else A)
+    return to_dense_u8(A, what)
+
+
 def to_dense_u8(X, what="X"):
     """ndarray / COO container -> C-contiguous uint8 [L,N,N,M]; counts must lie in [0,255]."""
     if is_sparse_like(X):
