@@ -23,7 +23,7 @@ def _network(L, N, M, K, xmax, seed, mask, dens=0.08):
     if mask == "ones":
         R = None
     elif mask == "words":      # long partial rows: bit-packed mask words
-        R = (g.rand(L, N, N, M) < 0.6).astype(np.uint8)
+        R = (g.rand(L, N, N, M) < 0.9).astype(np.uint8)
         R[:, :2] = 1           # some all-ones rows
         R[:, 2] = 0            # some empty ones
     else:                      # "lists": the self-reporter mask of survey data (short partial rows)
@@ -70,7 +70,7 @@ def test_more_than_eight_categories_substeps_and_sweeps(K, mask):
     """K in {9, 16, 21}: every sub-step from a seeded state, then fused sweeps with the ELBO, against the coordinate-list oracle;
     through the coordinate-list entry point and (all-ones / word masks) the dense one."""
     from vimure_amd import _lib
-    L, N, M = 2, 23, 23 if mask == "lists" else 11
+    L, N, M = 2, 23, {"lists": 23, "words": 80, "ones": 11}[mask]   # (rows of more than 64 reporters stay mask words)
     X, R = _network(L, N, M, K, 6, seed=K, mask=mask)
     for coo in ([True, False] if mask != "lists" else [True]):
         eng, c = _pair(X, R, K, True, seed=3, coo=coo)
@@ -101,7 +101,7 @@ def test_more_than_eight_categories_substeps_and_sweeps(K, mask):
 @pytest.mark.parametrize("K", [70, 130])
 def test_categories_beyond_one_wave(K):
     """K > 64: several categories per lane (NCH = 2 and 4 in k_sweep_gen)."""
-    X, R = _network(1, 12, 7, K, 4, seed=K, mask="words", dens=0.15)
+    X, R = _network(1, 12, 70, K, 4, seed=K, mask="words", dens=0.05)
     eng, c = _pair(X, R, K, True, seed=5)
     for _ in range(3):
         c.cavi_step()
@@ -112,7 +112,7 @@ def test_categories_beyond_one_wave(K):
 
 
 def test_mutuality_off_sixteen_categories():
-    X, R = _network(2, 20, 9, 16, 5, seed=8, mask="words")
+    X, R = _network(2, 20, 72, 16, 5, seed=8, mask="words", dens=0.03)
     eng, c = _pair(X, R, 16, False, seed=2)
     for _ in range(3):
         c.cavi_step()
@@ -205,10 +205,10 @@ def test_readout_and_sampler_with_twelve_categories():
     assert np.array_equal(eng.readout("rho_max"), rho.argmax(-1).astype(np.uint8))
     np.testing.assert_allclose(eng.readout("rho_mean"), (rho * np.arange(K)).sum(-1), rtol=1e-12)
     # the sampler: per tie the most frequent of n categorical trials; with many trials that is the arg max wherever it is clear
-    y = eng.sample(seed=5, n_trials=400)
+    y = eng.sample(seed=5, n_trials=4000)
     top2 = np.sort(rho, -1)[..., -2:]
-    clear = (top2[..., 1] - top2[..., 0]) > 0.25
-    assert clear.sum() > 20 and np.array_equal(y[clear], rho.argmax(-1)[clear].astype(np.uint8))
+    clear = (top2[..., 1] - top2[..., 0]) > 0.08   # (4000 trials: a margin of 320 counts against a deviation of ~35)
+    assert clear.sum() > 5 and np.array_equal(y[clear], rho.argmax(-1)[clear].astype(np.uint8))
     one = eng.sample(seed=6, n_trials=1)    # single draws: the category frequencies follow rho
     freq = np.bincount(one.ravel(), minlength=K) / one.size
     np.testing.assert_allclose(freq, rho.reshape(-1, K).mean(0), atol=4.0 / np.sqrt(one.size))

@@ -2458,7 +2458,15 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
   // packed ones cannot hold the tensor (a uint8 tensor always fits: 256 levels x Mp rows < 2^32)
   const bool need_lists = g.K > KMAX;
   if (need_lists && force_dense) return fail(nullptr, VMR_EINVAL, "VMR_FORMAT=dense: the dense tile kernels hold at most 8 categories");
-  const bool can_list = packed_ok || need_lists || force_sparse;   // (VMR_FORMAT=sparse: wide entries for what the packed ones cannot hold)
+  // ... and so do tensors the dense tiles cannot hold at all (their per-reporter tables outgrow the LDS: M of several thousand)
+  bool dense_fits = true;
+  {
+    Geo t = g;   // (what create_tail would settle on for the dense tiles)
+    t.Y = g.Y; t.hc = t.Y < HC_MAX ? t.Y : HC_MAX;
+    if (shmem_rho(t, true, false) > 80000) { t.two_pass = 1; while (t.hc > 0 && shmem_hist(t) > 160000) --t.hc; }
+    dense_fits = std::max(shmem_rho(t, true, true), shmem_hist(t)) <= (size_t)160 * 1024;
+  }
+  const bool can_list = packed_ok || need_lists || force_sparse || !dense_fits;   // (VMR_FORMAT=sparse: wide entries for what the packed ones cannot hold)
   if (!force_dense && can_list) {
     g.wide = packed_ok ? 0 : 1;
     unsigned* rp = nullptr;   // [L][T+1] per-tie entry offsets: only needed to place the entries
@@ -2480,7 +2488,7 @@ static int create_dense(vmr_ctx* h, const hipDeviceProp_t& prop, const uint8_t* 
     for (int l = 0; l < L; ++l) { h->nnz += nl[l]; fits = fits && nl[l] < 0xffffffffull; }
     const double sparse_bytes = 4.0 * (double)h->nnz + 4.0 * (double)rows, dense_bytes = (double)rows * g.Mp;
     if (need_lists && !fits) { (void)hipFree(rp); return fail(nullptr, VMR_EINVAL, "more than 2^32 reports in one layer"); }
-    h->sparse = fits && (force_sparse || need_lists || sparse_bytes <= 0.5 * dense_bytes);
+    h->sparse = fits && (force_sparse || need_lists || !dense_fits || sparse_bytes <= 0.5 * dense_bytes);
     if (!h->sparse) g.wide = 0;
     g.gen = (h->sparse && (need_lists || g.wide)) ? 1 : 0;
     if (h->sparse) {
