@@ -79,10 +79,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps sweeps; value = the median block")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (roofline then has no live launch time)")
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_layer / small_fits blocks after the timed region")
-    ap.add_argument("--extra-seconds", type=float, default=90.0, help="time budget of the extra blocks")
+    ap.add_argument("--extra-seconds", type=float, default=150.0, help="time budget of the extra blocks")
     ap.add_argument("--c5-nodes", type=int, default=8000, help="--config c5: nodes per layer (the stated configuration is 8000; smaller only to rehearse)")
-    ap.add_argument("--villages", type=int, default=16, help="--config c4: synthetic villages (x 4 layers x --seeds fits)")
-    ap.add_argument("--seeds", type=int, default=3, help="--config c4: seeds per (village, layer)")
+    ap.add_argument("--villages", type=int, default=75, help="--config c4: villages of the Karnataka table (x 4 layers x --seeds fits); 75 = the stated workload")
+    ap.add_argument("--seeds", type=int, default=10, help="--config c4: seeds per (village, layer); the reference's driver runs 10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (bounded sample)")
     ap.add_argument("--format", default="auto", choices=["auto", "dense", "sparse"],
@@ -253,6 +253,10 @@ def main():
             out["time_to_converge"] = time_to_converge(cfg, net, eng, seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_full_size"] = cpu_baseline(cfg, net, R, host, pr, args.cpu_seconds, eng)
+            try:
+                out["cpu_baseline_sparse"] = cpu_baseline_sparse(cfg, net, host, pr, args.cpu_seconds, out["parity_full_size"])
+            except Exception as e:
+                out["cpu_baseline_sparse"] = {"error": repr(e)}
         eng.close()
         del net, R
         torch.cuda.empty_cache()
@@ -319,7 +323,7 @@ def c5_layer_block(device, N=8000, M=1000, K=3, sweeps=10):
             "elbo_after_sweeps": e, "setup_seconds": t_setup}
 
 
-def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600, 250, 350, 500, 550, 300, 400, 220, 280), n_seeds=3):
+def small_fits_block(device, budget_s, sizes=None, n_seeds=None):
     """BASELINE configs[3] shape (tools/bench_batch.py): Karnataka-like villages (self-reporter mask, M-dim = N, 4 layers fitted
     separately, K=2, 5 realisations x <= 101 iterations per fit; karnataka.py:170-191) through vimure_amd.batch from ONE
     process: the (village, layer) units -- 48 here; the reference's experiment has 300 -- advance in lockstep, one launch per kernel and sweep for all of them
@@ -329,13 +333,20 @@ def small_fits_block(device, budget_s, sizes=(200, 324, 450, 600, 250, 350, 500,
     from vimure_amd.synthetic import standard_sbm
     from vimure_amd.tensor import SparseTensor
     warnings.simplefilter("ignore")
-    data = {f"vil{v}": village_coo(N, v, f"cuda:{device}") for v, N in enumerate(sizes)}
+    # the stated workload -- 75 villages x 4 layers x 10 seeds = 3000 fits -- when the time budget allows (about 15 s of fits and as much
+    # set-up), else the first 12 villages x 3 seeds
+    full = sizes is None and budget_s >= 60.0
+    table = KARNATAKA_VILLAGES if full else (KARNATAKA_VILLAGES[:12] if sizes is None else [(n, None) for n in sizes])
+    n_seeds = n_seeds if n_seeds is not None else (10 if full else 3)
+    sizes = [n for n, _ in table]
+    data = {f"vil{v}": village_coo(N, v, f"cuda:{device}", n_resp=nr) for v, (N, nr) in enumerate(table)}
     fit_datasets({"w": data["vil0"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=device)   # warm-up
     t0 = time.perf_counter()
     df = fit_datasets(data, K=2, seeds=range(n_seeds), num_realisations=5, max_iter=101, workers=HOST_WORKERS, device=device)
     dt = time.perf_counter() - t0
     sweeps = float(df["iters"].sum())   # (iterations of the best realisation only: a lower bound on the sweeps run)
-    return {"workload": f"{len(sizes)} villages N={list(sizes)} x 4 layers x {n_seeds} seeds, 5 realisations x <= 101 iterations each",
+    return {"workload": f"{len(sizes)} villages (Karnataka table: N = {min(sizes)}..{max(sizes)}, respondents as measured) x 4 layers x {n_seeds} seeds, "
+                        "5 realisations x <= 101 iterations each" + (" = BASELINE configs[3] as stated" if full else ""),
             "fits": int(len(df)), "seconds": dt, "fits_per_s": len(df) / dt, "processes": 1, "host_threads": HOST_WORKERS, "lockstep_units": 4 * len(sizes),
             "mean_fit_seconds": float(df["seconds"].mean()), "sweeps_per_s_lower_bound": sweeps / dt}
 
@@ -371,25 +382,50 @@ def bench_c5_sharded(args, rank, world, local, dev, dist, N=8000, M=1000, K=3, c
     dist.destroy_process_group()
 
 
-def village_coo(N, seed, dev, L=4):
+# The 75 villages of the reference's Karnataka data (data/input/india_microfinance/formatted/vil*_edges.csv), measured
+# in the build container: (nodes N = distinct i / j of the edge list, respondents = distinct `respondent`).  Data statistics only --
+# the workload shape of BASELINE configs[3]: every village x 4 layers (karnataka.py:15 LAYERS) x 10 seeds (karnataka.py:21) fits.
+KARNATAKA_VILLAGES = [
+    (198, 94), (326, 142), (390, 195), (337, 150), (472, 212), (369, 178), (448, 199), (661, 284), (559, 243), (417, 203), (343, 159),
+    (495, 210), (639, 280), (437, 211), (688, 303), (317, 149), (353, 174), (774, 395), (623, 303), (414, 203), (359, 170), (386, 200),
+    (627, 301), (429, 219), (321, 181), (386, 216), (590, 293), (263, 132), (376, 182), (720, 370), (671, 344), (527, 266), (353, 181),
+    (415, 206), (447, 227), (519, 258), (541, 263), (577, 279), (364, 160), (447, 217), (387, 184), (506, 255), (522, 261), (620, 309),
+    (856, 395), (375, 170), (261, 124), (575, 279), (294, 148), (467, 239), (474, 216), (811, 387), (338, 164), (898, 413), (311, 155),
+    (493, 242), (407, 190), (619, 294), (750, 341), (425, 189), (512, 230), (360, 164), (490, 220), (219, 110), (528, 233), (695, 298),
+    (525, 238), (447, 217), (386, 193), (472, 210), (579, 269), (338, 172), (388, 172), (231, 109), (523, 246)]
+
+
+def village_coo(N, seed, dev, L=4, n_resp=None):
     """A Karnataka-shaped village as the reader delivers it -- coordinate containers of X and of the self-reporter mask R (R[l,i,j,m]
-    = 1 iff m is i or j, `_io.py:230-242`) -- drawn on the device (the host generator needs minutes for N = 800) and masked there."""
+    = 1 iff m is i or j AND m is a respondent, `_io.py:230-242`; the reporter dimension is N, `_io.py:230,253`) -- drawn on the
+    device (the host generator needs minutes for N = 800) and masked there.  n_resp: how many of the N nodes answered the survey
+    (None: all of them)."""
     import torch
     from vimure_amd.synthetic import standard_sbm
     from vimure_amd.tensor import SparseTensor
     net = standard_sbm(N=N, M=N, L=L, K=2, avg_degree=3.0, eta=0.3, seed=seed, device=dev)
-    idx = torch.nonzero(net.X)   # row-major order, as np.nonzero
-    idx = idx[(idx[:, 3] == idx[:, 1]) | (idx[:, 3] == idx[:, 2])]
+    resp = np.ones(N, bool)
+    if n_resp is not None and n_resp < N:
+        resp[:] = False
+        resp[np.random.RandomState(1000 + seed).choice(N, size=int(n_resp), replace=False)] = True
+    resp_d = torch.as_tensor(resp, device=dev)
+    parts = []
+    for l in range(L):   # (layer by layer: torch.nonzero fails beyond 2^31 elements, and 4 x 898^3 is more)
+        il = torch.nonzero(net.X[l])   # row-major order, as np.nonzero
+        il = il[((il[:, 2] == il[:, 0]) | (il[:, 2] == il[:, 1])) & resp_d[il[:, 2]]]
+        parts.append(torch.cat([torch.full((il.shape[0], 1), l, dtype=il.dtype, device=il.device), il], dim=1))
+    idx = torch.cat(parts, dim=0)
     vals = net.X[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]].cpu().numpy().astype(np.int64)
     X = SparseTensor(tuple(idx[:, d].cpu().numpy() for d in range(4)), vals, shape=(L, N, N, N))
     del net, idx
     torch.cuda.empty_cache()
     ll, ii, jj = (a.ravel() for a in np.meshgrid(np.arange(L), np.arange(N), np.arange(N), indexing="ij"))
     lo, hi = np.minimum(ii, jj), np.maximum(ii, jj)
-    keep = np.ones(2 * len(ll), bool)
-    keep[1::2] = lo != hi   # (i == j: one reporter)
+    mm = np.stack([lo, hi], axis=1).ravel()
+    keep = resp[mm]
+    keep[1::2] &= (lo != hi)   # (i == j: one reporter)
     rep2 = lambda a: np.repeat(a, 2)[keep]
-    mm = np.stack([lo, hi], axis=1).ravel()[keep]
+    mm = mm[keep]
     R = SparseTensor((rep2(ll), rep2(ii), rep2(jj), mm), np.ones(len(mm), np.int64), shape=(L, N, N, N))
     return X, R
 
@@ -402,11 +438,10 @@ def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
     from vimure_amd.synthetic import standard_sbm
     from vimure_amd.tensor import SparseTensor
     warnings.simplefilter("ignore")
-    g = np.random.RandomState(0)
-    sizes = g.randint(200, 801, size=args.villages)   # the measured village sizes of the reference's data: N ~ 200-800
+    table = KARNATAKA_VILLAGES[:max(1, min(args.villages, len(KARNATAKA_VILLAGES)))]   # the stated workload: all 75
     data = {}
-    for v, N in enumerate(sizes):
-        data[f"vil{v:02d}"] = village_coo(int(N), v, dev)
+    for v, (N, nresp) in enumerate(table):
+        data[f"vil{v:02d}"] = village_coo(int(N), v, dev, n_resp=int(nresp))
     fit_datasets({"w": data["vil00"]}, K=2, seeds=range(1), num_realisations=1, max_iter=11, workers=4, device=local)   # warm-up
     if dist is not None:
         dist.barrier()
@@ -427,7 +462,8 @@ def bench_c4_batch(args, rank, world, local, dev, dist, cdev=None):
                           "value": len(df) / dt, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / max(1, len(df)), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                           "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"BASELINE configs[3] shape: {args.villages} villages (N=M in 200..800, self-reporter mask) x 4 "
+                          "config": {"workload": f"BASELINE configs[3]: {len(table)} villages (node and respondent counts of the reference's 75 "
+                                                 f"Karnataka villages, N = 198..898, reporter dimension N, self-reporter mask) x 4 "
                                                  f"layers x {args.seeds} seeds = {len(df)} fits, sharded over {world} rank(s)",
                                      "rccl_world": world}}), flush=True)
     if dist is not None:
@@ -516,6 +552,39 @@ def cpu_baseline(cfg, net, R, host, pr, budget_s, eng):
               "nu_shp_rel": abs(st["nu_shp"] - c.nu_shp) / abs(c.nu_shp),
               "rho_max_abs": float(np.max(np.abs(st["rho"] - c.rho)))}
     return base, parity
+
+
+def cpu_baseline_sparse(cfg, net, host, pr, budget_s, parity):
+    """The like-for-like CPU figure: oracle/cavi_coo.c -- the same algorithm class as the engine (coordinate lists of the non-zero
+    counts, all-ones mask implicit; OpenMP over ties) -- on the same inputs and initial state, same box, bounded sample.  Its
+    set-up (sorting the lists, the mirror counts) is outside the timing, as vmr_create's is outside the engine's."""
+    import torch
+    from oracle import cavi_coo
+    L, N, M, K = cfg["L"], cfg["N"], cfg["M"], cfg["K"]
+    idx = torch.nonzero(net.X)
+    vals = net.X[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]].cpu().numpy().astype(np.int32)
+    subs = tuple(idx[:, d].cpu().numpy() for d in range(4))
+    del idx
+    t0 = time.perf_counter()
+    c = cavi_coo.CooRef((subs, vals), None, (L, N, N, M), K, cfg["mutuality"], (0.1, 0.1, 10.0, 10.0, 0.5, 1.0),
+                        host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+    t_prep = time.perf_counter() - t0
+    cores = c.threads()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        c.cavi_step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200 or el / n * (n + 1) > 2 * budget_s:
+            break
+    out = {"value": n / el, "unit": "iter/s", "cores": cores, "kind": "port",
+           "sample": f"{n} full sweeps (gamma,phi,rho,nu; no ELBO) of the same workload with oracle/cavi_coo.c (coordinate lists of the "
+                     f"{len(vals)} non-zero counts, OpenMP, {cores} threads), {el:.1f} s; list set-up {t_prep:.1f} s not counted"}
+    if n == parity.get("sweeps"):   # the two oracles after the same number of sweeps from the same state
+        out["elbo"] = c.elbo()
+        out["elbo_rel_diff_to_dense_oracle"] = abs(out["elbo"] - parity["elbo_cpu_oracle"]) / abs(parity["elbo_cpu_oracle"])
+    return out
 
 
 if __name__ == "__main__":

@@ -99,3 +99,65 @@ def test_lockstep_with_several_layers_and_five_categories():
             np.testing.assert_allclose(st2[k], st1[k], rtol=1e-9, atol=1e-12, err_msg=k)
         eng.close()
     del net
+
+
+def _oracle_loop(c, max_iter, tol, decision):
+    """The reference's stop rule (model.py:1021-1056) around the coordinate-list oracle: ELBO at iteration 1, every 10th, the last."""
+    it, coincide, reached, elbo, rows = 1, 0, False, -1e10, []
+    while not reached and it <= max_iter:
+        c.cavi_step()
+        if it == 1 or it % 10 == 0 or it == max_iter:
+            old, elbo = elbo, c.elbo()
+            coincide = coincide + 1 if abs(elbo - old) < tol else 0
+            reached = coincide > decision
+        it += 1
+        if (it - 1) % 10 == 0:
+            rows.append((it - 1, elbo))
+    return rows, elbo, it - 1, reached
+
+
+def _against_oracle(units, K, max_iter):
+    """units: [(X, R)] coordinate containers -> lockstep loop of all of them, each held to cavi_coo from the same drawn state."""
+    from bench import draw_state
+    from oracle import cavi_coo
+    from vimure_amd import CaviEngine
+    engs, refs = [], []
+    for s, (X, R) in enumerate(units):
+        L, N, M = int(X.shape[0]), int(X.shape[1]), int(X.shape[3])
+        eng = CaviEngine.from_coo(X.subs, X.vals, X.shape, R=R.subs, K=K, mutuality=True)
+        sum_x, cov = eng.data_stats()
+        host, pr = draw_state(dict(L=L, N=N, M=M, K=K, mutuality=True), 40 + s, sum_x, cov)
+        eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+        eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+        engs.append(eng)
+        refs.append(cavi_coo.CooRef((X.subs, np.asarray(X.vals).astype(np.int32)), R.subs, X.shape, K, True, (0.1, 0.1, 10.0, 10.0, 0.5, 1.0),
+                                    host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr))
+    res = CaviEngine.fit_loop_batch(engs, max_iter, 0.1, 1)
+    for eng, c, (rows, elbo, its, conv) in zip(engs, refs, res):
+        o_rows, o_elbo, o_its, o_conv = _oracle_loop(c, max_iter, 0.1, 1)
+        assert its == o_its and conv == o_conv and [r[0] for r in rows] == [r[0] for r in o_rows]
+        np.testing.assert_allclose([r[1] for r in rows], [r[1] for r in o_rows], rtol=1e-9)
+        assert abs(elbo - o_elbo) <= 1e-9 * abs(o_elbo)
+        st = eng.get_state(rho=True)
+        np.testing.assert_allclose(st["rho"], c.rho, rtol=1e-7, atol=1e-12)
+        for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte"):
+            np.testing.assert_allclose(st[k], getattr(c, k), rtol=1e-9, err_msg=k)
+        assert abs(st["nu_shp"] - c.nu_shp) <= 1e-9 * abs(c.nu_shp)
+        eng.close()
+
+
+def test_lockstep_at_the_largest_village_against_the_oracle():
+    """BASELINE configs[3]'s upper sizes through the lockstep launch: the largest Karnataka village (N = 898 nodes, 413 respondents,
+    reporter dimension N, self-reporter mask, L = 1) beside a median and the smallest one, every unit against oracle/cavi_coo.c."""
+    from bench import village_coo
+    from vimure_amd.tensor import layer_of
+    units = []
+    for s, (N, nresp) in enumerate([(898, 413), (447, 217), (198, 94)]):
+        X, R = village_coo(N, 50 + s, "cuda:0", L=1, n_resp=nresp)
+        units.append((layer_of(X, 0), layer_of(R, 0)))
+    _against_oracle(units, 2, 21)
+
+
+def test_lockstep_three_categories_two_layers_against_the_oracle():
+    """K = 3, L = 2 units in one lockstep launch, each against the oracle (not only against its own single loop)."""
+    _against_oracle([_village(N, 60 + s, K=3, L=2) for s, N in enumerate([44, 57, 70])], 3, 31)
