@@ -244,3 +244,46 @@ def test_subnormal_normaliser_is_divided_not_inverted():
     assert np.all(np.isfinite(g))
     np.testing.assert_allclose(g, c.rho, rtol=1e-9, atol=1e-300)
     eng.close()
+
+
+@pytest.mark.parametrize("mask", ["ones", "self"])
+def test_rho_of_inner_sweeps_is_not_written_and_nothing_can_tell(mask, monkeypatch):
+    """vmr_step(n) writes rho on its last sweep only (the rho of an inner sweep is overwritten unread: a dead store of a third of the
+    pass' bytes).  n sweeps in one call == n calls of one sweep; and with VMR_DEBUG_LAZY_RHO=1 -- not even the last sweep writes
+    -- every reader of rho (vmr_get_state, vmr_readout, vmr_elbo, vmr_snapshot) gets the same values through ensure_rho's re-write."""
+    from vimure_amd import CaviEngine
+    from vimure_amd.synthetic import standard_sbm
+    L, N, K = 2, 150, 2
+    M = N if mask == "self" else 20
+    net = standard_sbm(N=N, M=M, L=L, K=K, avg_degree=4.0, eta=0.4, seed=13, flag_self_reporter=(mask == "self"))
+    R = net.R if mask == "self" else None
+    g = np.random.RandomState(2)
+    pr = 1.0 + 0.01 * g.rand(L, N, N, K)
+    pr /= pr.sum(-1)[..., None]
+    init = (0.1 + 0.1 * g.rand(L, M), 0.1 + 0.1 * g.rand(L, M), 10 + 10 * g.rand(L, K), 10 + 10 * g.rand(L, K), 0.7, 1.0 + float(net.X.sum()), pr)
+
+    def run(mode):
+        eng = CaviEngine(net.X, R, K=K, mutuality=True)
+        assert eng.data_format()[0] == "sparse"
+        eng.set_priors(0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
+        eng.set_state(*init)
+        if mode == "one by one":
+            for _ in range(6):
+                eng.step(1)
+        else:
+            eng.step(6)
+        out = (eng.readout("rho_mean"), eng.get_state(), eng.elbo())
+        eng.snapshot(); eng.restore()
+        out += (eng.get_state()["rho"],)
+        eng.close()
+        return out
+    a = run("one by one")
+    b = run("one call")
+    monkeypatch.setenv("VMR_DEBUG_LAZY_RHO", "1")
+    c = run("one call")
+    for other in (b, c):
+        np.testing.assert_allclose(other[0], a[0], rtol=1e-11, atol=1e-14)
+        for k in ("rho", "gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):
+            np.testing.assert_allclose(other[1][k], a[1][k], rtol=1e-11, atol=1e-14, err_msg=k)
+        assert abs(other[2] - a[2]) <= 1e-11 * abs(a[2])
+        np.testing.assert_allclose(other[3], a[1]["rho"], rtol=1e-11, atol=1e-14)

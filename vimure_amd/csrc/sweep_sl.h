@@ -58,6 +58,7 @@ struct SlArgs {
   // the constant C (H_0 = C - D - sum_{k>0} H_k, D: the deficits of ties whose rho does not sum to 1), left there by
   // k_fin_gamma.  null: the pass does not touch nu.
   double* nu_acc; double* elbo_dev; int commit_nu;
+  int nu_stale;   // the factor table from the nu BEFORE its last update (SC_G_NU_STALE): the pass that re-writes the rho of the last sweep (ensure_rho)
   // Deterministic mode (Geo::det): every sum that crosses workgroups is added as a 64-bit integer in fixed point (integer adds
   // commute exactly) into these shadows -- [L][Y][Mp][K] H | [L][W*64][K] mask sums | [L][K] rho over all-ones rows | 4 ELBO
   // partials | 1 nu share -- which k_det_fold turns into the doubles the finalize kernels read.  Inside a workgroup nothing
@@ -94,7 +95,8 @@ static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elb
          (size_t)g.W * 8 + 128 + (g.ml ? lb + (size_t)g.Mp * 8 : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
 }
 
-// mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2)
+// mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2),
+//       4 = rho update (+ H) without writing rho (sweep_body's STORE = false)
 typedef int (*sl_launch_fn)(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a);
 sl_launch_fn vmr_sl_launcher(int K);   // null when K was not compiled in
 // mode 0 / 1 (rho update / + ELBO data terms) of the units' sweeps in one launch on `st`; units / blk_unit: device memory

@@ -60,7 +60,10 @@ template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 
 
 // The sweep over one handle's lists.  bx / gx: this workgroup's index in, and the size of, the handle's grid -- the whole launch
 // (k_sweep_sl) or a handle's share of a launch that serves many small handles (k_sweep_sl_b).
-template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+// STORE = false (update without ELBO only): the new rho is used -- for the statistics H, the mask sums, nu -- and NOT written.  A rho
+// that no one can read before the next sweep overwrites it is a dead store of a third of the pass' bytes: vmr_step / the fit loops
+// write rho on the last sweep of a call and on ELBO sweeps only (vmr_ctx::rho_stale, ensure_rho in vimure_hip.hip).
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
 __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const unsigned bx, const unsigned gx) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
@@ -206,7 +209,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // The factor table of the rho update, F[y][m][k] = (E log theta_m + E log lambda_k) w1_k(m, y) (model.py:685-693, 911-921), for
   // the levels this launch keeps in LDS: a few divides per thread from the per-reporter tables -- no global table, no kernel
   // that builds one.  Reports of levels beyond take the same formula on the fly (f_far).
-  const double gnu_f = a.par[o.sc + SC_G_NU];
+  const double gnu_f = a.par[o.sc + (a.nu_stale ? SC_G_NU_STALE : SC_G_NU)];   // (nu_stale: rho of the LAST sweep once more, ensure_rho)
   if (UPDATE) {
     for (int q = tid; q < (int)ytm; q += nthr) {
       const int y = q / Mp, m = q - y * Mp;
@@ -532,7 +535,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       }
       // exactly NST store instructions on every path, no mask (the wait at the bottom of the step counts on it): positions
       // past the last tie write their (finite) values into the slack rows behind the array
-      store_k<K>(act ? at_bytes(rl + row0 * K, laneK8) : at_bytes(rho_slack, laneK8), r);
+      if (STORE) store_k<K>(act ? at_bytes(rl + row0 * K, laneK8) : at_bytes(rho_slack, laneK8), r);
       if (act && (ALLFULL || cls == 1u)) {
 #pragma unroll
         for (int k = 0; k < K; ++k) accF[k] += r[k];
@@ -618,7 +621,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     // how many requests are younger than the ones it needs it drains them all: memory latency in every step.)  This step's rho
     // store is younger than the requests and need not have landed: the counter is in order, so "all but the NST youngest"
     // covers exactly the loads -- every path through a step issues exactly NST store instructions (see there).
-    constexpr int NST = UPDATE ? (K % 2 == 0 ? K / 2 : K) : 0;
+    constexpr int NST = (UPDATE && STORE) ? (K % 2 == 0 ? K / 2 : K) : 0;
     static_assert(NST <= 8, "vmcnt immediate below");
     if (RCT >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);   // vmcnt(NST)
     else __builtin_amdgcn_s_waitcnt(0x0F70);                  // (general steps may add global atomics: vmcnt(0))
@@ -768,7 +771,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       }
     }
   }
-  if (UPDATE || (!ELBO && a.do_hist == 1)) {
+  if ((UPDATE || (!ELBO && a.do_hist == 1)) && a.slotF) {   // (slotF null: a pass that only re-writes rho, ensure_rho)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       double v = block_sum_n(accF[k], red);
@@ -792,28 +795,28 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 
 #define SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) \
   __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL, UPDATE))
-template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
 __global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl(SlArgs a, Geo g) {
-  sweep_body<K, UPDATE, ELBO, ALLFULL>(a, g, blockIdx.x, gridDim.x);
+  sweep_body<K, UPDATE, ELBO, ALLFULL, STORE>(a, g, blockIdx.x, gridDim.x);
 }
 // One launch for many small handles in lockstep (vmr_fit_loop_batch): workgroup -> unit through `blk_unit`, the unit's
 // arguments from device memory.  A sweep of a Karnataka-sized layer is two dependent 20-40 us launches that leave the GPU
 // nearly empty; here every unit's sweep shares them.
-template <int K, bool UPDATE, bool ELBO, bool ALLFULL>
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
 __global__ __launch_bounds__(sl_tpb_max_b(K, ELBO, ALLFULL), sl_wpe_b(K, ELBO, ALLFULL)) void k_sweep_sl_b(const SlUnit* __restrict__ units, const int* __restrict__ blk_unit) {
   const SlUnit& u = units[blk_unit[blockIdx.x]];
-  sweep_body<K, UPDATE, ELBO, ALLFULL>(u.a, u.g, blockIdx.x - (unsigned)u.blk0, (unsigned)u.nblk);
+  sweep_body<K, UPDATE, ELBO, ALLFULL, STORE>(u.a, u.g, blockIdx.x - (unsigned)u.blk0, (unsigned)u.nblk);
 }
 
 // ------------------------------------------------------------------------------------------
 // launcher of this object's K
 // ------------------------------------------------------------------------------------------
-template <bool UPDATE, bool ELBO, bool ALLFULL>
+template <bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
 static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
   constexpr int K = VMR_K;
   const Geo& g = h->g;
   const long long NS = ((long long)g.N * g.N + 63) / 64, nw = sh.tpb / 64;
-  int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
+  int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
   if (rc) return rc;
 #ifdef SL_DEBUG
   // VMR_DEBUG_TIMES=<file>: every launch appends "<update><elbo> <waves>" and one line of four clock readings per wave
@@ -826,7 +829,7 @@ static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
     if (nwv * 32 <= ((size_t)1 << 22)) a.dbg_t = dbg_buf;
   }
 #endif
-  hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
+  hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
 #ifdef SL_DEBUG
   if (a.dbg_t) {
     std::vector<unsigned long long> t(nwv * 4);
@@ -850,6 +853,7 @@ int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlAr
       case 0: return sl_launch_one<true, false, true>(h, sh, a);
       case 1: return sl_launch_one<true, true, true>(h, sh, a);
       case 2: return sl_launch_one<false, true, true>(h, sh, a);
+      case 4: return sl_launch_one<true, false, true, false>(h, sh, a);   // (rho update, rho not written)
       default: return sl_launch_one<false, false, true>(h, sh, a);
     }
   }
@@ -857,26 +861,29 @@ int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlAr
     case 0: return sl_launch_one<true, false, false>(h, sh, a);
     case 1: return sl_launch_one<true, true, false>(h, sh, a);
     case 2: return sl_launch_one<false, true, false>(h, sh, a);
+    case 4: return sl_launch_one<true, false, false, false>(h, sh, a);
     default: return sl_launch_one<false, false, false>(h, sh, a);
   }
 }
 
 // the rho update (mode 0), rho update + ELBO data terms (mode 1) or the statistics of the current rho (mode 3: a realisation's
 // first sweep) of `nblocks` workgroups' worth of units in one launch
-template <bool UPDATE, bool ELBO, bool ALLFULL>
+template <bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
 static int sl_launch_batch_one(vmr_ctx* h, hipStream_t st, const SlUnit* units, const int* blk_unit, int nblocks, int tpb, size_t smem) {
   constexpr int K = VMR_K;
   // (the leave for > 48 KB of dynamic LDS is per device and this may be any thread's first launch there: asked for every time --
   // a call that costs nothing beside a batch's launches -- instead of remembered in a process-wide static)
   if (smem > 48 * 1024)
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL, STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL, STORE>), dim3(nblocks), dim3(tpb), smem, st, units, blk_unit);
   return VMR_OK;
 }
 int SL_CAT(vmr_sl_launch_batch_k, VMR_K)(vmr_ctx* h, hipStream_t st, int mode, int allfull, const SlUnit* units, const int* blk_unit, int nblocks,
                                           int tpb, size_t smem) {
   if (mode == 3) return allfull ? sl_launch_batch_one<false, false, true>(h, st, units, blk_unit, nblocks, tpb, smem)
                                 : sl_launch_batch_one<false, false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
+  if (mode == 4) return allfull ? sl_launch_batch_one<true, false, true, false>(h, st, units, blk_unit, nblocks, tpb, smem)
+                                : sl_launch_batch_one<true, false, false, false>(h, st, units, blk_unit, nblocks, tpb, smem);
   if (allfull) return mode ? sl_launch_batch_one<true, true, true>(h, st, units, blk_unit, nblocks, tpb, smem)
                            : sl_launch_batch_one<true, false, true>(h, st, units, blk_unit, nblocks, tpb, smem);
   return mode ? sl_launch_batch_one<true, true, false>(h, st, units, blk_unit, nblocks, tpb, smem)

@@ -1842,10 +1842,28 @@ static int det_fold(vmr_ctx* h) {
   return VMR_OK;
 }
 
+// The last sweep used its new rho without writing it (launch_rho, store = false): write it now -- the same update once more, from the
+// same log prior, theta, lambda and the nu of before that sweep's commit (SC_G_NU_STALE); no statistics, no sums, nothing else
+// changes.  Called by everything that reads rho; vmr_step and the fit loops leave no stale rho behind, so this only runs after a
+// loop that failed half way.
+static int ensure_rho(vmr_ctx* h) {
+  if (!h->rho_stale) return VMR_OK;
+  const SlShape shs = sl_shape(h, true, false, false);
+  SlArgs as = sl_args(h, shs, 0, 0);
+  as.slotF = nullptr; as.slotA = nullptr;
+  as.nu_stale = h->g.mut ? 1 : 0;
+  int rc = sl_launch(h, 0, shs, as);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  h->rho_stale = false;
+  return VMR_OK;
+}
+
 // nu: -1 = the pass leaves nu alone; 0 = it leaves the raw sum in elbo_dev[1]; 1 = it also commits nu (sorted lists, see SlArgs::nu_acc)
 static int launch_hist(vmr_ctx* h, int nu = -1) {
   const Geo& g = h->g;
   if (g.gen) return gen_hist(h);
+  { int rce = ensure_rho(h); if (rce) return rce; }
   HIPCHK(h, hipMemsetAsync(h->Hg, 0, (size_t)g.L * NH * g.Y * g.Mp * g.K * 8, h->stream));
   if (h->sparse) {
     HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));   // (the pass sums rho over all-ones mask rows)
@@ -1963,7 +1981,8 @@ static int launch_phi(vmr_ctx* h) {
 
 // mode: 0 = rho update (+nu), 1 = rho update + fused ELBO, 2 = ELBO only
 // raw_nu: leave the raw nu sum in elbo_dev[1] although nu is not committed (vmr_sweep_local)
-static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false) {
+// store = false (mode 0 on report lists in one pass only): the pass uses its new rho without writing it (vmr_ctx::rho_stale)
+static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false, bool store = true) {
   const Geo& g = h->g;
   if (g.gen) return gen_rho(h, mode, commit_nu, raw_nu, [](vmr_ctx* hh, int do_nu, int do_elbo, int skip_nu) { return launch_fin_rho(hh, do_nu, do_elbo, skip_nu); });
   RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, 1};
@@ -1977,6 +1996,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
   if (mode != 2) h->h_zero = false;
   // sorted lists with mutuality: the pass that builds H finishes nu itself -- no finalize launch on plain sweeps
   const bool nu_in_pass = h->sparse && g.mut && mode != 2 && (commit_nu || raw_nu);
+  if (mode == 2 && (rc = ensure_rho(h))) return rc;
   if (h->sparse) {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
@@ -1987,7 +2007,13 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false)
     SlArgs as = sl_args(h, shs, do_hist, sum_a);
     if (nu_in_pass && do_hist) { as.nu_acc = h->nu_acc; as.elbo_dev = h->elbo_dev; as.commit_nu = commit_nu ? 1 : 0; }
     as.det = g.det ? h->det_buf : nullptr;
-    if ((rc = sl_launch(h, mode, shs, as))) return rc;
+    // the rho of a sweep that the next one overwrites unread is not written: only with mutuality's nu committed inside the pass
+    // (the re-write of ensure_rho takes the nu before that commit from SC_G_NU_STALE) or without mutuality, in one pass per sweep
+    // -- and only where the pass itself sums rho over the mask rows: the mask kernels of launch_gamma read rho from memory
+    const bool lazy = !store && mode == 0 && do_hist && !g.det && (nu_in_pass ? commit_nu : !g.mut) && g.fuse_full && (h->n_partial == 0 || g.ml) &&
+                      !getenv("VMR_ALWAYS_STORE_RHO");
+    if ((rc = sl_launch(h, lazy ? 4 : mode, shs, as))) return rc;
+    if (mode != 2) h->rho_stale = lazy;
     if ((rc = det_fold(h))) return rc;
   } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
@@ -2960,6 +2986,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_state = true;
   h->restored = false;
+  h->rho_stale = false;
   h->h_valid = false;
   h->f_valid = false;
   h->a_valid = false;
@@ -2974,10 +3001,10 @@ static int read_elbo(vmr_ctx* h, double* out) {
   return VMR_OK;
 }
 
-static int sweep(vmr_ctx* h, int mode) {
+static int sweep(vmr_ctx* h, int mode, bool store = true) {
   int rc;
   if ((rc = launch_gamma(h, true))) return rc;   // gamma and phi are finished by one kernel
-  return launch_rho(h, mode, true);
+  return launch_rho(h, mode, true, false, store);
 }
 
 // After a committed sweep the handle is in a fixed point of its bookkeeping: the next sweep is the same three or four
@@ -3008,11 +3035,18 @@ static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
   return VMR_OK;
 }
 
+// n sweeps.  rho is written by the LAST sweep of the call (and by ELBO sweeps) only: the rho of a sweep inside the call is overwritten
+// by the next one before anyone can read it.  store_last = false: the caller runs an ELBO sweep next (the fit loops), so not even that.
+static int step_n(vmr_ctx* h, int n_iters, double* elbo_out, bool store_last);
 int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_step");
   if (h->restored) return fail(h, VMR_ESTATE, "vmr_step after vmr_restore: the restored state is read-only until the next vmr_set_state");
   if (n_iters < 0) return fail(h, VMR_EINVAL, "n_iters < 0");
+  // (VMR_DEBUG_LAZY_RHO=1, diagnostics / tests: leave even the call's last rho unwritten, so that every reader goes through ensure_rho)
+  return step_n(h, n_iters, elbo_out, getenv("VMR_DEBUG_LAZY_RHO") == nullptr);
+}
+static int step_n(vmr_ctx* h, int n_iters, double* elbo_out, bool store_last) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   int it = 0;
@@ -3028,8 +3062,8 @@ int vmr_step(vmr_handle h, int n_iters, double* elbo_out) {
     }
   }
   for (; it < n_iters; ++it) {
-    bool last = (it == n_iters - 1) && elbo_out;
-    if ((rc = sweep(h, last ? 1 : 0))) return rc;
+    const bool last = it == n_iters - 1;
+    if ((rc = sweep(h, (last && elbo_out) ? 1 : 0, last && store_last))) return rc;
   }
   if (elbo_out) {
     if (n_iters == 0) return vmr_elbo(h, elbo_out);
@@ -3050,13 +3084,13 @@ static int fit_loop_core(vmr_ctx* h, LoopState& st, int max_iter, double tol, in
     const int it = st.it;
     const int nxt = (it == 1 || it % 10 == 0 || it == max_iter) ? it : std::min(max_iter, (it / 10 + 1) * 10);
     if (nxt > it) {
-      if ((rc = vmr_step(h, nxt - it, nullptr))) return rc;
+      if ((rc = step_n(h, nxt - it, nullptr, false))) return rc;   // (an ELBO sweep follows: it writes rho)
       st.it = nxt;
       HIPCHK(h, hipStreamSynchronize(h->stream));   // so that the runtime below is this iteration's sweep, as in the reference
     }
     const auto t0 = std::chrono::steady_clock::now();
     const double old = st.elbo;
-    if ((rc = vmr_step(h, 1, &st.elbo))) return rc;
+    if ((rc = step_n(h, 1, &st.elbo, true))) return rc;
     const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     st.coincide = (fabs(st.elbo - old) < tol) ? st.coincide + 1 : 0;
     if (st.coincide > decision) st.reached = 1;
@@ -3263,9 +3297,12 @@ int vmr_fit_loop_batch(vmr_handle* hs, int n, int max_iter, double tol, int deci
   std::vector<double> be_host((size_t)n * 8);
   int rc = batch_tables(hs, act, n, bt, st);
   if (rc) return rc;
+  const bool lazy_rho = !getenv("VMR_ALWAYS_STORE_RHO");   // plain sweeps do not write rho: the ELBO sweep every loop ends with does
   auto launch_sweeps = [&](int mode) -> int {
     hipLaunchKernelGGL(k_fin_gamma_b, dim3(bt.ngb), dim3(FIN_TPB), bt.fsm, st, bt.fu, bt.gmap, bt.fg);
-    int r = pass(h0, st, mode, allfull, bt.su[mode], bt.smap[mode], bt.nb[mode], bt.tpb[mode], bt.smem[mode]);
+    const int pm = (mode == 0 && lazy_rho) ? 4 : mode;
+    int r = pass(h0, st, pm, allfull, bt.su[mode], bt.smap[mode], bt.nb[mode], bt.tpb[mode], bt.smem[mode]);
+    for (int u : act) hs[u]->rho_stale = pm == 4;
     if (r) return r;
     if (mode == 1) hipLaunchKernelGGL(k_fin_rho_b, dim3(bt.nrb), dim3(TPB), 0, st, bt.fu, bt.rmap);
     HIPCHK(h0, hipGetLastError());
@@ -3401,6 +3438,7 @@ int vmr_sub_step(vmr_handle h, int which) {
   if (h->restored) return fail(h, VMR_ESTATE, "vmr_sub_step after vmr_restore: the restored state is read-only until the next vmr_set_state");
   HIPCHK(h, hipSetDevice(h->device));
   if (h->g.det) return fail(h, VMR_ESTATE, "vmr_sub_step is not available with VMR_DETERMINISTIC=1 (whole sweeps only: vmr_step, vmr_fit_loop)");
+  { const int rce = ensure_rho(h); if (rce) return rce; }
   switch (which) {
     case VMR_STEP_GAMMA: return launch_gamma(h, false);
     case VMR_STEP_PHI: return launch_phi(h);
@@ -3445,6 +3483,7 @@ int vmr_get_state(vmr_handle h, double* gamma_shp, double* gamma_rte, double* ph
     if (nu_rte) *nu_rte = buf[o.sc + SC_NU_RTE];
   }
   if (rho) {
+    { const int rce = ensure_rho(h); if (rce) return rce; }
     const size_t nr = (size_t)g.L * g.N * g.N * g.K;
     const double* src = h->rho;
     if (h->perm) {   // back to tie order
@@ -3478,6 +3517,7 @@ int vmr_snapshot(vmr_handle h) {
   if (!h) return VMR_EINVAL;
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_snapshot");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rce = ensure_rho(h); if (rce) return rce; }
   const Geo& g = h->g;
   const size_t nr = (size_t)g.L * g.N * g.N * g.K * 8, np_ = h->par_doubles * 8;
   if (!h->rho_snap) { HIPCHK(h, hipMalloc(&h->rho_snap, nr)); HIPCHK(h, hipMalloc(&h->par_snap, np_)); }
@@ -3497,6 +3537,7 @@ int vmr_restore(vmr_handle h) {
   HIPCHK(h, hipMemcpyAsync(h->par, h->par_snap, h->par_doubles * 8, hipMemcpyDeviceToDevice, h->stream));
   h->h_valid = false; h->f_valid = false; h->a_valid = false; h->h_zero = false;
   h->restored = true;   // the log prior on the device is the LAST realisation's: reading is fine, sweeping is not
+  h->rho_stale = false;
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   hipLaunchKernelGGL(k_build_lut, dim3(g.L), dim3(256), 0, h->stream, h->par, h->lutg, g);
   HIPCHK(h, hipGetLastError());
@@ -3508,6 +3549,7 @@ int vmr_readout(vmr_handle h, int method, double threshold, void* out, int out_o
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_readout");
   if (method < VMR_READ_RHO_MAX || method > VMR_READ_THRESHOLD) return fail(h, VMR_EINVAL, "unknown read-out method");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rce = ensure_rho(h); if (rce) return rce; }
   const Geo& g = h->g;
   const size_t ties = (size_t)g.L * g.N * g.N, bytes = ties * (method == VMR_READ_RHO_MEAN ? 8 : 1);
   void* dst = out;
@@ -3528,6 +3570,7 @@ int vmr_sample(vmr_handle h, uint64_t seed, int n_trials, uint8_t* out, int out_
   if (!h->have_state) return fail(h, VMR_ESTATE, "vmr_set_state must be called before vmr_sample");
   if (n_trials < 1) return fail(h, VMR_EINVAL, "n_trials must be positive");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rce = ensure_rho(h); if (rce) return rce; }
   const Geo& g = h->g;
   const size_t T_ = (size_t)g.N * g.N, ties = (size_t)g.L * T_;
   uint8_t* dst = out;
