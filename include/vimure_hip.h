@@ -232,6 +232,22 @@ int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz);
  * those lists.  The bit-packed mask is kept either way.  Either pointer may be NULL. */
 int vmr_mask_format(vmr_handle h, int* lists, uint64_t* listed);
 
+/* Synthetic generators on the device (no handle: they produce the inputs of vmr_create).
+ * vmr_generate_y replaces the ground-truth draw of the reference's StandardSBM (synthetic.py:548-571, 639-667):
+ * Y[l,i,j] ~ Poisson(w[grp[i]][grp[j]]) clipped to K - 1, zero diagonal.  w [C][C] and grp [N] are host arrays, Y_dev a
+ * uint8 [L][N][N] array in device memory.
+ * vmr_generate_x replaces `_build_X` (synthetic.py:63-352; the pair-wise draw :159-231): for every unordered pair a fair coin
+ * picks the direction drawn first, first ~ Poisson((own + eta * mirror) / (1 - eta^2)), second ~ Poisson(own + eta * first), with
+ * own = lambda * theta[l,m] in float64; lambda from Y_dev (0.01 where Y = 0, else Y, or 0.01 + lambda_diff when lambda_diff > 0;
+ * synthetic.py:140-157) or given as lam_dev (double [L][N][N], device; Y_dev may then be NULL).  theta [L][M] is a host array.
+ * self_reporter != 0: only a tie's own two nodes report (`_io.py:230-242`; M == N) and X_dev must come zeroed.
+ * X_dev: uint8 [L][N][N][M] in device memory, counts clamped to 255 -- what vmr_create(data_on_device = 1) takes.
+ * Counter-based stream (Philox4x32-10 keyed by seed; counter = layer, pair, reporter): a draw depends on (seed, l, i, j, m) only.
+ * NOT the reference's RandomState stream: the host classes keep that exact mode (vimure_amd/synthetic.py).  Both synchronise. */
+int vmr_generate_y(int device, int L, int N, int K, int C, const double* w, const int32_t* grp, uint64_t seed, uint8_t* Y_dev);
+int vmr_generate_x(int device, int L, int N, int M, const uint8_t* Y_dev, const double* lam_dev, const double* theta, double eta,
+                   double lambda_diff, uint64_t seed, int self_reporter, uint8_t* X_dev);
+
 /* Library/version string. */
 const char* vmr_version(void);
 

@@ -145,3 +145,74 @@ def test_posterior_predictive_network_is_the_references():
     assert np.array_equal(pn.X.toarray(), G["post_X"]) and np.array_equal(pn.R.toarray(), G["post_R"])
     pn.build_X(flag_self_reporter=False, cutoff_X=True, seed_X=6, exact=True)
     assert np.array_equal(pn.X.toarray(), G["post_X_ones"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sbm", "sbm_nosparse", "dcsbm"])
+def test_device_generator_kernel_against_the_references_draws_by_moments(name):
+    """The HIP generator (csrc/generate.hip, vmr_generate_x) draws `_build_X` (reference synthetic.py:159-231) from a Philox stream,
+    so it is held to the REFERENCE's own output (fixture K, dumped from the real `_build_X`) statistically: over 300 seeds, per
+    (layer, reporter): the mean count, the density of non-zero counts and the reciprocity sum_ij X_ij X_ji of the reference's draw
+    must lie inside the kernel's distribution (inside the range of the 300 draws cell by cell, |z| < 4.5 pooled over a layer's
+    reporters), and the ensemble mean of every cell must match the analytic mean (lambda theta + eta mirror) / (1 - eta^2) within 5 standard errors."""
+    import torch
+    theta, lam = G[f"{name}_theta"], G[f"{name}_lambda_k"]
+    eta, self_rep = float(G[f"{name}_build_mutuality"]), bool(G[f"{name}_build_flag_self_reporter"])
+    Xref = G[f"{name}_X"].astype(np.float64)
+    if f"{name}_build_cutoff_X" in G and bool(G[f"{name}_build_cutoff_X"]):
+        pytest.skip("the fixture's draw was cut off at Q - 1 (a host-side step after the draw)")
+    L, N, _, M = Xref.shape
+    lam_d = torch.as_tensor(lam, device="cuda:0", dtype=torch.float64)
+    n = 300
+    acc = np.zeros(Xref.shape)
+    stats = np.zeros((n, 3, L, M))
+
+    def st(X):
+        return np.stack([X.mean(axis=(1, 2)), (X > 0).mean(axis=(1, 2)), (X * X.transpose(0, 2, 1, 3)).sum(axis=(1, 2))])
+    for s in range(n):
+        X = sy.device_build_x(None, theta, eta, 1000 + s, lam=lam_d, flag_self_reporter=self_rep).cpu().numpy().astype(np.float64)
+        assert np.all(X[:, np.arange(N), np.arange(N)] == 0)
+        if self_rep:
+            R = sy.self_reporter_mask(L, N, M)
+            assert np.all(X[R == 0] == 0)
+        acc += X
+        stats[s] = st(X)
+    ref = st(Xref)
+    # per (statistic, layer, reporter): counts this small are far from normal -- the reference's value must lie inside the range the
+    # 300 draws span, up to the few exceedances 3 L M such comparisons produce by chance (2 / 301 each)
+    outside = int(((ref < stats.min(0)) | (ref > stats.max(0))).sum())
+    assert outside <= 4 + 3 * ref.size // 100, (outside, ref.size)
+    # pooled over the reporters of a layer the statistics are sums of hundreds of terms: a z-test against the ensemble's spread
+    pooled, pref = stats.sum(axis=3), ref.sum(axis=2)
+    z = (pref - pooled.mean(0)) / (pooled.std(0) + 1e-12)
+    assert np.all(np.abs(z) < 4.5), z
+    MX = theta[:, None, None, :] * lam[..., None]
+    MM = (MX + eta * MX.transpose(0, 2, 1, 3)) / (1.0 - eta * eta)
+    if self_rep:
+        MM = MM * sy.self_reporter_mask(L, N, M)
+    MM[:, np.arange(N), np.arange(N)] = 0.0
+    var = MM * (1.0 + 0.5 * eta * eta * 2.0) + 1e-12      # (a mixture of a Poisson and a Poisson given a Poisson: a little over-dispersed)
+    err = np.abs(acc / n - MM) / np.sqrt(var / n)
+    assert err.max() < 6.0, float(err.max())
+    assert abs(acc.sum() / n - MM.sum()) <= 5.0 * np.sqrt(var.sum() / n)
+
+
+@pytest.mark.gpu
+def test_device_generator_is_a_function_of_the_seed_and_fills_the_engine():
+    """Same seed, same tensor (whatever the launch); the Y kernel's block structure; large rates (PTRS branch) by their mean."""
+    import torch
+    from vimure_amd.synthetic import standard_sbm
+    a = standard_sbm(N=150, M=40, L=2, K=3, avg_degree=6.0, eta=0.4, seed=5, device="cuda:0")
+    b = standard_sbm(N=150, M=40, L=2, K=3, avg_degree=6.0, eta=0.4, seed=5, device="cuda:0")
+    c = standard_sbm(N=150, M=40, L=2, K=3, avg_degree=6.0, eta=0.4, seed=6, device="cuda:0")
+    assert torch.equal(a.X, b.X) and torch.equal(a.Y, b.Y) and not torch.equal(a.X, c.X)
+    Y = a.Y.cpu().numpy()
+    assert Y.max() <= 2 and np.all(Y[:, np.arange(150), np.arange(150)] == 0)
+    grp = np.minimum(np.arange(150) // 75, 1)
+    same = grp[:, None] == grp[None, :]
+    assert Y[:, same].mean() > 4 * Y[:, ~same].mean()          # assortative: ten times the ties inside a group
+    big = sy.device_build_x(None, np.full((1, 64), 3.0), 0.2, 7, lam=torch.full((1, 40, 40), 40.0, device="cuda:0", dtype=torch.float64))
+    m = big.cpu().numpy().astype(float)
+    off = ~np.eye(40, dtype=bool)
+    expect = (120.0 + 0.2 * 120.0) / (1 - 0.04)
+    assert abs(m[0][off].mean() - expect) < 0.02 * expect and m.max() <= 255

@@ -25,6 +25,12 @@ def main(path):
         print("  step loop   ", q(us[:, 2] - us[:, 1]))
         print("  epilogue    ", q(us[:, 3] - us[:, 2]))
         print("  end         ", q(us[:, 3]))
+        if t.shape[1] >= 8:
+            print("  prologue: first loads issued", q(us[:, 4] - us[:, 0]), "| tables' barrier", q(us[:, 5] - us[:, 0]))
+            print("  epilogue: nu share done     ", q(us[:, 6] - us[:, 2]), "| flush done", q(us[:, 7] - us[:, 2]))
+        tail = us[:, 3] - us[:, 7]
+        print("  after the flush (ticket, sums, finalize tail of the layer-last workgroups): p50 %.1f  p99 %.1f  max %.1f; 8 longest:" % (
+            np.median(tail), np.percentile(tail, 99), tail.max()), np.round(np.sort(tail)[-8:], 1), "kernel end", round(us[:, 3].max(), 1))
         nw = int(head.split("tpb")[1]) // 64
         wg_end = us[:, 2].reshape(-1, nw)
         print("  loop end per workgroup: first/last wave spread (p50, max) us: %.1f %.1f" % (np.median(wg_end.max(1) - wg_end.min(1)), (wg_end.max(1) - wg_end.min(1)).max()))

@@ -26,7 +26,8 @@ def units(dev=False):
     extra = ["-DVMR_DEV"] if dev else []
     u = [("vimure_hip", os.path.join(CSRC, "vimure_hip.hip"), extra),
          ("sorted_lists", os.path.join(CSRC, "sorted_lists.hip"), extra),
-         ("sweep_gen", os.path.join(CSRC, "sweep_gen.hip"), extra)]   # the general kernels: any K, wide entries
+         ("sweep_gen", os.path.join(CSRC, "sweep_gen.hip"), extra),   # the general kernels: any K, wide entries
+         ("generate", os.path.join(CSRC, "generate.hip"), extra)]     # the synthetic generators on the device
     dev_ks = tuple(int(k) for k in os.environ.get("VMR_DEV_KS", "2").split(","))   # (VMR_DEV_KS=2,3: also the K = 3 sweep kernels)
     for k in (dev_ks if dev else KS):
         u.append((f"sweep_sl_k{k}", os.path.join(CSRC, "sweep_sl.hip"), extra + [f"-DVMR_K={k}"]))

@@ -65,7 +65,7 @@ struct SlArgs {
   // needs it: a workgroup is ONE wave there and walks a fixed share of the steps in order.  null: floating-point atomics.
   unsigned long long* det;
 #ifdef SL_DEBUG
-  unsigned long long* dbg_t;   // [waves][4]: a wave's start, end of prologue, end of step loop, end (100 MHz clock)
+  unsigned long long* dbg_t;   // [waves][8]: a wave's start, end of prologue, end of step loop, end; first loads issued, tables' barrier, nu share done, flush done (100 MHz clock)
 #endif
 };
 

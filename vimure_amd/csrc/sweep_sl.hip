@@ -88,7 +88,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = (int)bx / a.Gl, gb = (int)bx - l * a.Gl;
 #ifdef SL_DEBUG
-  unsigned long long* dbt = a.dbg_t ? a.dbg_t + ((size_t)bx * nw + wv) * 4 : nullptr;
+  unsigned long long* dbt = a.dbg_t ? a.dbg_t + ((size_t)bx * nw + wv) * 8 : nullptr;
   if (dbt && lane == 0) dbt[0] = wall_clock64();
 #endif
   const size_t T = (size_t)g.N * g.N;
@@ -204,8 +204,14 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     fetch_tie(P, s);
     fetch_ent(P, ea, RC<PFK>{});
   }
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[4] = wall_clock64();
+#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step finds nothing of its own outstanding (see the wait in `body`)
   __syncthreads();   // per-reporter tables
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[5] = wall_clock64();
+#endif
   // The factor table of the rho update, F[y][m][k] = (E log theta_m + E log lambda_k) w1_k(m, y) (model.py:685-693, 911-921), for
   // the levels this launch keeps in LDS: a few divides per thread from the per-reporter tables -- no global table, no kernel
   // that builds one.  Reports of levels beyond take the same formula on the fly (f_far).
@@ -671,6 +677,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (a.det) atomicAdd(&det_R()[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
     }
   }
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[6] = wall_clock64();
+#endif
   // the flush: every wave but the first when the first draws the ticket (it then has nothing else of its own outstanding)
   const int f0 = (nu_here && nw > 1) ? 64 : 0;
 #ifdef SL_DEBUG
@@ -692,6 +701,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (v != 0.0) { if (a.det) atomicAdd(&det_A()[q], det_fx(v, DET_SH_A)); else atomicAdd(&out[q], v); }
     }
   }
+#ifdef SL_DEBUG
+  if (dbt && lane == 0) dbt[7] = wall_clock64();
+#endif
   if (nu_here) {
     // the ticket; the grid's last workgroup finishes nu (model.py:820-830)
     __shared__ int nu_last;
@@ -826,18 +838,18 @@ static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
   a.dbg_t = nullptr;
   if (tf) {
     if (!dbg_buf) (void)hipMalloc(&dbg_buf, (size_t)1 << 22);
-    if (nwv * 32 <= ((size_t)1 << 22)) a.dbg_t = dbg_buf;
+    if (nwv * 64 <= ((size_t)1 << 22)) a.dbg_t = dbg_buf;
   }
 #endif
   hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
 #ifdef SL_DEBUG
   if (a.dbg_t) {
-    std::vector<unsigned long long> t(nwv * 4);
+    std::vector<unsigned long long> t(nwv * 8);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipMemcpy(t.data(), dbg_buf, nwv * 32, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(t.data(), dbg_buf, nwv * 64, hipMemcpyDeviceToHost);
     if (FILE* f = fopen(tf, "a")) {
       fprintf(f, "launch %d%d hist %d waves %zu tpb %d\n", (int)UPDATE, (int)ELBO, a.do_hist, nwv, sh.tpb);
-      for (size_t i = 0; i < nwv; ++i) fprintf(f, "%llu %llu %llu %llu\n", t[i * 4], t[i * 4 + 1], t[i * 4 + 2], t[i * 4 + 3]);
+      for (size_t i = 0; i < nwv; ++i) fprintf(f, "%llu %llu %llu %llu %llu %llu %llu %llu\n", t[i * 8], t[i * 8 + 1], t[i * 8 + 2], t[i * 8 + 3], t[i * 8 + 4], t[i * 8 + 5], t[i * 8 + 6], t[i * 8 + 7]);
       fclose(f);
     }
   }

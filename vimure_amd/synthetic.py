@@ -93,57 +93,69 @@ def standard_sbm(N=100, M=100, L=1, K=2, C=2, avg_degree=2.0, sparsify=True, eta
         X = np.minimum(X, 255).astype(np.uint8)
         return SyntheticNetwork(X, R, Y, theta, lam, eta, K)
 
+    # On the GPU: the HIP generator kernels (csrc/generate.hip through the C-ABI: vmr_generate_y, vmr_generate_x) -- float64 rates,
+    # a counter-based Philox stream, the uint8 tensor vmr_create takes written once.  torch only holds the device memory.
+    Y, _ = device_sbm_y(L, N, K, C, w * ((float(N) * avg_degree) / MY.sum() if sparsify else 1.0), grp, seed, device)
+    X = device_build_x(None, theta, eta, seed, Y=Y, lambda_diff=lambda_diff, flag_self_reporter=flag_self_reporter)
     import torch
-    dev = torch.device(device)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(int(seed))
-    th = torch.as_tensor(theta, device=dev, dtype=torch.float32)
-    MYt = torch.as_tensor(MY, device=dev, dtype=torch.float32)
-    X = torch.zeros((L, N, N, M), dtype=torch.uint8, device=dev)
-    Ys, lams = [], []
-    # row blocks small enough that a [B,B,M] float32 temporary stays near 2 GB (config 5: N=8000, M=1000 -> B=724)
-    B = int(min(N, max(1, int((block_bytes / (4.0 * M)) ** 0.5))))
-    starts = list(range(0, N, B))
-    for l in range(L):
-        Y = torch.poisson(MYt, generator=gen)
-        Y.fill_diagonal_(0)
-        Y.clamp_(max=K - 1)
-        lam = torch.where(Y > 0, torch.full_like(Y, 0.01 + lambda_diff) if lambda_diff is not None else Y,
-                          torch.full_like(Y, 0.01))
-        for bi, i0 in enumerate(starts):
-            i1 = min(N, i0 + B)
-            for j0 in starts[bi:]:
-                j1 = min(N, j0 + B)
-                MXa = lam[i0:i1, j0:j1, None] * th[l][None, None, :]            # block (I,J)
-                MXb = lam[j0:j1, i0:i1, None] * th[l][None, None, :]            # block (J,I)
-                Aa = torch.poisson((MXa + eta * MXb.transpose(0, 1)) / (1.0 - eta * eta), generator=gen)
-                # on a diagonal block (J,I) IS (I,J): one draw serves both directions
-                Ab = Aa if i0 == j0 else torch.poisson((MXb + eta * MXa.transpose(0, 1)) / (1.0 - eta * eta), generator=gen)
-                Ba = torch.poisson(MXa + eta * Ab.transpose(0, 1), generator=gen)   # second draw given the mirror's first
-                Bb = torch.poisson(MXb + eta * Aa.transpose(0, 1), generator=gen)
-                coin = torch.rand(MXa.shape, device=dev, generator=gen) < 0.5     # (i,j) drawn first, else (j,i)
-                gi = torch.arange(i0, i1, device=dev)[:, None, None]
-                gj = torch.arange(j0, j1, device=dev)[None, :, None]
-                up = gi < gj                                                      # i < j: this element leads its pair
-                lo = gi > gj
-                if i0 == j0:   # diagonal block: both triangles live in the same block
-                    coin_t = coin.transpose(0, 1)
-                    Xa = torch.where(up & coin, Aa, torch.where(up & ~coin, Ba,
-                         torch.where(lo & coin_t, Ba, torch.where(lo & ~coin_t, Aa, torch.zeros_like(Aa)))))
-                    X[l, i0:i1, j0:j1] = Xa.clamp_(max=255).to(torch.uint8)
-                else:          # every (i,j) of the block has i < j
-                    X[l, i0:i1, j0:j1] = torch.where(coin, Aa, Ba).clamp_(max=255).to(torch.uint8)
-                    X[l, j0:j1, i0:i1] = torch.where(coin.transpose(0, 1), Bb, Ab).clamp_(max=255).to(torch.uint8)
-                del MXa, MXb, Aa, Ab, Ba, Bb, coin
-        Ys.append(Y.to(torch.uint8))
-        lams.append(lam)
-    R = None
-    if flag_self_reporter:
-        R = torch.as_tensor(self_reporter_mask(L, N, M), device=dev)
-        X = X * R
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
-    return SyntheticNetwork(X, R, torch.stack(Ys), np.asarray(theta), torch.stack(lams), eta, K)
+    R = torch.as_tensor(self_reporter_mask(L, N, M), device=X.device) if flag_self_reporter else None
+    lam = torch.where(Y > 0, torch.full(Y.shape, 0.01 + lambda_diff, device=Y.device, dtype=torch.float64) if lambda_diff is not None
+                      else Y.to(torch.float64), torch.full(Y.shape, 0.01, device=Y.device, dtype=torch.float64))
+    return SyntheticNetwork(X, R, Y, np.asarray(theta), lam, eta, K)
+
+
+def _dev_index(device):
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("the device generators run on a GPU ('cuda[:i]')")
+    return d, (d.index if d.index is not None else torch.cuda.current_device())
+
+
+def device_sbm_y(L, N, K, C, w, grp, seed, device):
+    """Ground truth of a stochastic block model drawn on the GPU (vmr_generate_y).  w [C,C]: expected ties per ordered pair of
+    groups; grp [N]: group of every node.  Returns (Y uint8 [L,N,N], X uint8 [L,N,N,?] placeholder None) as torch tensors."""
+    import ctypes as C_
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    d, idx = _dev_index(device)
+    Y = torch.empty((L, N, N), dtype=torch.uint8, device=d)
+    torch.cuda.synchronize(d)
+    wq = np.ascontiguousarray(w, dtype=np.float64)
+    gq = np.ascontiguousarray(grp, dtype=np.int32)
+    rc = lib.vmr_generate_y(idx, int(L), int(N), int(K), int(C), wq.ctypes.data, gq.ctypes.data, int(seed) & (2 ** 64 - 1), Y.data_ptr())
+    if rc != 0:
+        raise RuntimeError(lib.vmr_last_error(None).decode())
+    return Y, None
+
+
+def device_build_x(X, theta, eta, seed, Y=None, lam=None, lambda_diff=None, flag_self_reporter=False, M=None):
+    """The reports X given the ground truth, drawn on the GPU (vmr_generate_x; reference `_build_X`, synthetic.py:159-231).
+    Y: uint8 torch tensor [L,N,N] on the GPU (lambda = 0.01 | Y | 0.01 + lambda_diff), or lam: float64 [L,N,N] (torch GPU tensor or
+    array).  X: None (allocated here) or a uint8 [L,N,N,M] GPU tensor.  Returns X."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    src = Y if Y is not None else lam
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    L, M_ = theta.shape
+    if lam is not None and not torch.is_tensor(lam):
+        raise ValueError("lam must be a torch tensor on the GPU")
+    d, idx = _dev_index(src.device)
+    N = int(src.shape[1])
+    if lam is not None:
+        lam = lam.to(torch.float64).contiguous()
+    if X is None:
+        X = (torch.zeros if flag_self_reporter else torch.empty)((L, N, N, M_), dtype=torch.uint8, device=d)
+    torch.cuda.synchronize(d)
+    rc = lib.vmr_generate_x(idx, int(L), N, int(M_), Y.data_ptr() if Y is not None else None, lam.data_ptr() if lam is not None else None,
+                            theta.ctypes.data, float(eta), float(lambda_diff) if lambda_diff is not None else -1.0,
+                            int(seed) & (2 ** 64 - 1), int(bool(flag_self_reporter)), X.data_ptr())
+    if rc != 0:
+        msg = lib.vmr_last_error(None).decode()
+        raise (ValueError if rc == _lib.VMR_EINVAL else RuntimeError)(msg)
+    return X
 
 
 # ======================================================================================================================
@@ -286,23 +298,11 @@ def _draw_vectorised(prng, theta, lambda_k, eta, flag_self_reporter, device=None
     L, N, _ = lambda_k.shape
     M = theta.shape[1]
     R = self_reporter_mask(L, N, M).astype(float) if flag_self_reporter else np.ones((L, N, N, M))
-    if device is not None:
+    if device is not None:   # the HIP generator kernel (vmr_generate_x): float64 rates, Philox stream keyed by a seed drawn from prng
         import torch
-        dev = torch.device(device)
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(int(prng.randint(0, 2 ** 31 - 1)))
-        th = torch.as_tensor(theta, device=dev)
-        lam = torch.as_tensor(lambda_k, device=dev)
-        Rt = torch.as_tensor(R, device=dev)
-        MX = lam[..., None] * th[:, None, None, :]
-        MXt = MX.transpose(1, 2)
-        A = torch.poisson((MX + eta * MXt) / (1.0 - eta * eta) * Rt, generator=gen)
-        B = torch.poisson(MX * Rt + eta * A.transpose(1, 2), generator=gen)
-        coin = torch.rand(MX.shape, device=dev, generator=gen) < 0.5
-        iu = torch.triu(torch.ones((N, N), dtype=torch.bool, device=dev), 1)[None, :, :, None]
-        first = (coin & iu) | (~coin & iu).transpose(1, 2)
-        X = torch.where(first, A, torch.where(first.transpose(1, 2), B, torch.zeros_like(A)))
-        return (X * (Rt > 0)).to(torch.int64), R
+        lam = torch.as_tensor(np.ascontiguousarray(lambda_k, dtype=np.float64), device=torch.device(device))
+        X = device_build_x(None, theta, eta, int(prng.randint(0, 2 ** 31 - 1)), lam=lam, flag_self_reporter=flag_self_reporter)
+        return X.to(torch.int64), R
     MX = theta[:, None, None, :] * lambda_k[..., None]
     MXt = MX.transpose(0, 2, 1, 3)
     A = prng.poisson((MX + eta * MXt) / (1.0 - eta * eta) * R)
