@@ -118,6 +118,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    if world > 1:
+        # every rank says where it runs (stderr): a rank that shares a device with another, or sees the wrong one, shows here
+        prop = torch.cuda.get_device_properties(local)
+        print(f"bench.py: rank {rank}/{world} on cuda:{local} ({prop.name}, {prop.multi_processor_count} CUs, {prop.total_memory >> 30} GiB), "
+              f"backend {dist.get_backend()}, world size observed {dist.get_world_size()}", file=sys.stderr, flush=True)
+        ids = [None] * world
+        dist.all_gather_object(ids, (local, torch.cuda.get_device_properties(local).uuid.__str__() if hasattr(prop, "uuid") else str(local)))
+        if rank == 0 and not rehearse and len({u for _, u in ids}) != world:
+            raise SystemExit(f"bench.py: {world} ranks but only {len({u for _, u in ids})} distinct devices: {ids}")
     if world > 1 and rank == 0:
         print(f"bench.py: RCCL world size {dist.get_world_size()} (backend {dist.get_backend()}), one rank per GPU", file=sys.stderr, flush=True)
     if args.config == "c5":
@@ -181,10 +190,18 @@ def main():
         blocks.append(time.perf_counter() - t0)
         elbo = e_ if e_ is not None else elbo
         it0 += args.steps
+    own_ms = 1e3 * float(np.median(blocks)) / args.steps   # this rank's own pace, before the MAX over ranks
+    per_rank_ms = [own_ms]
     if dist is not None:   # MAX over ranks, block by block
         tt = torch.tensor(blocks, dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         blocks = [float(v) for v in tt.tolist()]
+        pr_ = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(pr_, torch.tensor([own_ms], dtype=torch.float64, device=cdev))
+        per_rank_ms = [float(v.item()) for v in pr_]
+        if rank == 0 and max(per_rank_ms) > 1.10 * min(per_rank_ms):
+            # independent fits of the same dataset (weak scaling): every rank should run at the single-GPU pace
+            print(f"bench.py: WARNING ranks differ by more than 10 % in ms per sweep: {['%.4f' % v for v in per_rank_ms]}", file=sys.stderr, flush=True)
     dt = float(np.median(blocks))
     prof = eng.profile_read()
     eng.profile(False)
@@ -238,6 +255,7 @@ def main():
             "elbo": elbos, "gen_seconds": t_gen,
             "timing_blocks": {"repeats": len(blocks), "steps_per_block": args.steps, "median_s": dt, "min_s": min(blocks),
                               "max_s": max(blocks), "value_from": "median block"},
+            "per_rank_ms_per_step": per_rank_ms,   # each rank's own pace (weak scaling: every entry should equal the 1-GPU ms_per_step)
         }
         # whole-sweep view: SURVEY 8(d)'s canonical DENSE bytes per iteration (three passes over X,R + ELBO share)
         # against the wall time of a sweep.  The engine makes ONE pass per sweep (sufficient statistics) over report

@@ -178,3 +178,63 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible():
         assert np.all(np.abs(np.array(elbos) - ref) <= 1e-8 * np.maximum(1.0, np.abs(ref)))
         assert abs(maxL - float(d["fit_maxL"])) <= 1e-8 * abs(float(d["fit_maxL"]))
         np.testing.assert_allclose(nu_shp, d["fit_nu_shp_f"], rtol=1e-7)
+
+
+class _DeviceTensorsOverGloo:
+    """A stand-in for torch.distributed with ONE GPU shared by two ranks: it reports a backend other than gloo, so
+    `fit_layer_sharded` takes its device-resident branch (vmr_sweep_local_dev -> all_reduce on the engine's stream ->
+    vmr_commit_nu_dev), and carries the all-reduce of the CUDA tensor through the host over gloo.  Everything of the two-rank
+    exchange but RCCL itself."""
+
+    def __init__(self, dist):
+        self._d = dist
+
+    def get_backend(self):
+        return "nccl-stand-in"
+
+    def all_reduce(self, t, op=None):
+        c = t.detach().cpu()      # (on the current stream: inside `with torch.cuda.stream(ext)` that is the engine's own)
+        self._d.all_reduce(c)
+        t.copy_(c)
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+
+def _worker_dev(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from tests.golden_util import case_config, load_case
+    from vimure_amd.sharded import fit_layer_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = load_case("B_random_mask_K3")
+    K, mut, und, seed, priors, fitargs, rho_prior = case_config(d)
+    res = fit_layer_sharded(d["X"][rank:rank + 1], d["R"][rank:rank + 1], [rank], 2, K, _DeviceTensorsOverGloo(dist), seed=seed,
+                            mutuality=mut, device=0, **fitargs)
+    q.put((rank, [t[2] for t in res["trace"]], [t[3] for t in res["trace"]], res["maxL"], res["posterior"]["nu_shp"]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_device_resident_exchange_on_one_gpu():
+    """The device-resident exchange (the branch RCCL takes) with TWO ranks, on the one GPU of this box: the reference's joint
+    two-layer fit again (golden case B)."""
+    import torch.multiprocessing as mp
+    from tests.golden_util import load_case
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_dev, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = load_case("B_random_mask_K3")
+    for rank, iters, elbos, maxL, nu_shp in got:
+        assert iters == d["fit_trace_iter"].tolist()
+        ref = d["fit_trace_elbo"]
+        assert np.all(np.abs(np.array(elbos) - ref) <= 1e-8 * np.maximum(1.0, np.abs(ref)))
+        assert abs(maxL - float(d["fit_maxL"])) <= 1e-8 * abs(float(d["fit_maxL"]))
+        np.testing.assert_allclose(nu_shp, d["fit_nu_shp_f"], rtol=1e-7)

@@ -349,7 +349,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   };
   // H += x rho (+ the ELBO's log terms) over NP entries whose rows are all in LDS; an empty slot adds 0
   auto walk2_near = [&](const unsigned* e, auto npc, const double (&r)[K], const double (&er)[K]) SL_INL {
-    constexpr int NP = decltype(npc)::value, LG = 2;   // logarithms side by side (their chains interleave; more would spill)
+#ifndef SL_LG
+#define SL_LG 2
+#endif
+    constexpr int NP = decltype(npc)::value, LG = SL_LG;   // logarithms side by side (their chains interleave; more would spill)
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += LG) {
       double in_[LG];
