@@ -100,3 +100,34 @@ def test_deterministic_two_pass_regime_is_bit_equal(monkeypatch):
         assert np.array_equal(np.asarray(outs[0][1][k]), np.asarray(outs[1][1][k])), k
     del net
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", ["B_random_mask_K3", "D_self_mask", "A_ones_mut"])
+def test_deterministic_mode_against_the_oracle_and_the_reference(case, monkeypatch):
+    """The deterministic mode against something independent of the engine: the NumPy oracle's sweeps from the same state, and the
+    reference's own golden values (sub-step rho / ELBO of iteration 1..3) -- not only against itself and the default mode."""
+    from oracle import vimure_oracle as vo
+    from tests.golden_util import case_config, load_case
+    from vimure_amd import CaviEngine
+    monkeypatch.setenv("VMR_DETERMINISTIC", "1")
+    d = load_case(case)
+    K, mut, und, seed, priors, fitargs, rho_prior = case_config(d)
+    L, N, _, M = d["X"].shape
+    pr = vo.make_priors(L, M, K, **priors)
+    pb = vo.Problem(d["X"], d["R"], K, mut, pr, undirected=und)
+    st = vo.init_state(pb, np.random.RandomState(seed), rho_prior=rho_prior)
+    eng = CaviEngine(d["X"], d["R"], K=K, mutuality=mut)
+    eng.set_priors(pr.alpha_theta, pr.beta_theta, pr.alpha_lambda, pr.beta_lambda, pr.alpha_eta, pr.beta_eta)
+    eng.set_state(st.gamma_shp, st.gamma_rte, st.phi_shp, st.phi_rte, st.nu_shp, st.nu_rte, st.pr_rho)
+    for it in range(1, len(d["step_elbo"]) + 1):
+        e = eng.step(1, want_elbo=True)
+        vo.cavi_step(pb, st)
+        eo, er = vo.elbo(pb, st), float(d["step_elbo"][it - 1])
+        assert abs(e - eo) <= 1e-9 * max(1.0, abs(eo)) and abs(e - er) <= 1e-9 * max(1.0, abs(er)), (it, e, eo, er)
+        g = eng.get_state()
+        np.testing.assert_allclose(g["rho"], d[f"it{it}_rho"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(g["gamma_shp"], d[f"it{it}_gamma_shp"], rtol=1e-9)
+        np.testing.assert_allclose(g["phi_rte"], d[f"it{it}_phi_rte"], rtol=1e-9)
+        if mut:
+            np.testing.assert_allclose(g["nu_shp"], d[f"it{it}_nu_shp"], rtol=1e-9)
+    eng.close()

@@ -63,7 +63,11 @@ template <int K> struct Batch { static constexpr int value = K <= 2 ? SL_BATCH2 
 // STORE = false (update without ELBO only): the new rho is used -- for the statistics H, the mask sums, nu -- and NOT written.  A rho
 // that no one can read before the next sweep overwrites it is a dead store of a third of the pass' bytes: vmr_step / the fit loops
 // write rho on the last sweep of a call and on ELBO sweeps only (vmr_ctx::rho_stale, ensure_rho in vimure_hip.hip).
-template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
+// DET (VMR_DETERMINISTIC=1, SlArgs::det): every sum whose order would vary from run to run -- which wave takes which step, which
+// atomic lands first -- is an INTEGER sum in fixed point: the LDS statistics and mask sums (64-bit LDS adds), the per-lane sums over
+// ties (rho over all-ones rows, the ELBO partials), the cross-workgroup shadows.  Integer adds commute exactly, so the workgroups
+// keep their 16 waves and their tickets (rounds 2-3 ran this mode with ONE wave per workgroup: 4.5 times slower).
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true, bool DET = false>
 __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const unsigned bx, const unsigned gx) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
@@ -112,11 +116,25 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
   for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; Lla[k] = a.par[o.l_la + l * K + k]; }
   const double eps = g.eps;
+  // fixed point of the deterministic mode: v * 2^sh rounded to nearest through the 1.5 * 2^52 trick (|v| 2^sh < 2^51: the host caps
+  // det_sh at 40 and det_shr at 34 -- counts hold 11 bits, ELBO terms 16 -- and keeps DET_SH_A = 30 for sums of rho)
+  const double sc_h = DET ? __builtin_amdgcn_ldexp(1.0, g.det_sh) : 0.0, sc_r = DET ? __builtin_amdgcn_ldexp(1.0, g.det_shr) : 0.0;
+  const double sc_a = DET ? __builtin_amdgcn_ldexp(1.0, DET_SH_A) : 0.0;
+  auto fxm = [](double v, double scale) SL_INL -> unsigned long long {
+    return (unsigned long long)(__double_as_longlong(fma(v, scale, 6755399441055744.0)) - 0x4338000000000000ll);
+  };
+  auto lds_add = [&](double* p, double v, double scale) SL_INL {   // an LDS cell: a double, or (DET) a 64-bit fixed-point integer
+    if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(p), fxm(v, scale)); else atomicAdd(p, v);
+  };
   const float rcp_mp = 1.0f / (float)Mp;
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accF[k] = 0.0;
+  // (DET: the same sums as integers -- a lane's ties depend on the tickets its wave drew)
+  unsigned long long ie_lin = 0ull, ie_q = 0ull, ie_log = 0ull, iaccF[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) iaccF[k] = 0ull;
   double* Hl = a.Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
   // deterministic mode: the integer shadows (SlArgs::det), located where they are used (nothing of this lives across the step loop)
   auto det_H = [&]() SL_INL { return a.det + (size_t)l * g.Y * Mp * K; };
@@ -244,12 +262,12 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         if (__all(!v || (int)m == m0)) {   // one reporter for the whole wave (ties (i, j..j+63)): one add instead of 64 on one address
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const double sm_ = wave_sum(v ? rr[k] : 0.0);
-            if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
+            const double sm_ = wave_sum(v ? rr[k] : 0.0);   // (fixed lanes, fixed ties: the same sum every run)
+            if (lane == 0) lds_add(&As[m0 * K + k], sm_, sc_a);
           }
         } else if (v) {
 #pragma unroll
-          for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
+          for (int k = 0; k < K; ++k) lds_add(&As[m * K + k], rr[k], sc_a);
         }
       }
       return;
@@ -266,11 +284,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const double sm_ = wave_sum(v ? rr[k] : 0.0);
-          if (lane == 0) atomicAdd(&As[m0 * K + k], sm_);
+          if (lane == 0) lds_add(&As[m0 * K + k], sm_, sc_a);
         }
       } else if (v) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) atomicAdd(&As[m * K + k], rr[k]);
+        for (int k = 0; k < K; ++k) lds_add(&As[m * K + k], rr[k], sc_a);
       }
     }
   };
@@ -363,14 +381,17 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
           const double dx = (double)SL_X(e[j0 + u]);
           if (a.do_hist) {
 #pragma unroll
-            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)k * hcm + ym], dx * r[k]);
+            for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
           }
           if (ELBO) in_[u] = elbo_inner(e[j0 + u], er);
         }
       }
       if (ELBO) {
 #pragma unroll
-        for (int u = 0; u < LG; ++u) if (j0 + u < NP) e_log += (double)SL_X(e[j0 + u]) * log_tab(in_[u], lt);
+        for (int u = 0; u < LG; ++u) if (j0 + u < NP) {
+          const double term = (double)SL_X(e[j0 + u]) * log_tab(in_[u], lt);
+          if (DET) ie_log += fxm(term, sc_r); else e_log += term;
+        }
         __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every group's table reads and chains to the top: spills)
       }
     }
@@ -379,7 +400,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // edges of BASELINE config 5 -- 1000 reports each, every exponential underflows, the reference's all-zero rows -- sent 40 M
   // adds per pass to a few thousand addresses of the global table when this was a global add.)
   auto deficit = [&](unsigned ent, double dfc) SL_INL {   // (a step whose rows all lie in the LDS levels)
-    atomicAdd(&Hc[SL_YM(ent)], (double)SL_X(ent) * dfc);
+    lds_add(&Hc[SL_YM(ent)], (double)SL_X(ent) * dfc, sc_h);
   };
   // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
   auto body = [&](auto rct) SL_INL {
@@ -547,7 +568,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (STORE) store_k<K>(act ? at_bytes(rl + row0 * K, laneK8) : at_bytes(rho_slack, laneK8), r);
       if (act && (ALLFULL || cls == 1u)) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) accF[k] += r[k];
+        for (int k = 0; k < K; ++k) { if (DET) iaccF[k] += fxm(r[k], sc_a); else accF[k] += r[k]; }
       }
       if (!ALLFULL && a.sum_a) add_lists(tie, act && cls == 2u, r);
     } else if (a.do_hist) {
@@ -561,7 +582,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (irr && lane == 0) tick[1] = 1u;
       if (!ELBO && a.do_hist == 1 && act && (ALLFULL || cls == 1u)) {   // all-ones mask rows are summed here too
 #pragma unroll
-        for (int k = 0; k < K; ++k) accF[k] += r[k];
+        for (int k = 0; k < K; ++k) { if (DET) iaccF[k] += fxm(r[k], sc_a); else accF[k] += r[k]; }
       }
       if (!ALLFULL && !ELBO && a.sum_a) add_lists(tie, act && cls == 2u, r);
     }
@@ -590,17 +611,17 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
           if (a.do_hist) {
             const unsigned row = fr ? 0u : ym;
 #pragma unroll
-            for (int k = 1; k < K; ++k) atomicAdd(&Hc[(unsigned)k * hcm + row], dx * r[k]);
-            if (irr) atomicAdd(&Hc[row], dx * dfc);   // (wave-uniform: some tie of the step does not sum to 1)
+            for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + row], dx * r[k], sc_h);
+            if (irr) lds_add(&Hc[row], dx * dfc, sc_h);   // (wave-uniform: some tie of the step does not sum to 1)
             if (__any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
               if (fr && x != 0u) {   // table by the grid's last workgroup (nu_far).
-                if (a.det) {
+                if (DET) {
                   unsigned long long* d0 = a.det;
                   asm volatile("" : "+s"(d0));   // (keeps this address arithmetic inside the rare branch: hoisted, it cost every variant ten registers)
                   unsigned long long* d = d0 + (size_t)l * g.Y * Mp * K + (size_t)ym * K;
 #pragma unroll
-                  for (int k = 1; k < K; ++k) atomicAdd(&d[k], det_fx((double)x * r[k], g.det_sh));
-                  if (dfc != 0.0) atomicAdd(&d[0], det_fx((double)x * dfc, g.det_sh));
+                  for (int k = 1; k < K; ++k) atomicAdd(&d[k], fxm((double)x * r[k], sc_h));
+                  if (dfc != 0.0) atomicAdd(&d[0], fxm((double)x * dfc, sc_h));
                 } else {
                   double* d = Hl + (size_t)ym * K;
 #pragma unroll
@@ -611,7 +632,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
               asm volatile("" ::: "memory");
             }
           }
-          if (ELBO) e_log += (double)x * log_tab(elbo_inner(c, er), lt);
+          if (ELBO) { const double term = (double)x * log_tab(elbo_inner(c, er), lt); if (DET) ie_log += fxm(term, sc_r); else e_log += term; }
         });
       }
     }
@@ -622,8 +643,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         sr += r[k]; se += r[k] * Ela[k];
         en += r[k] * cur.v[k] - r[k] * log_tab(r[k] + eps, lt);   // model.py:1306-1313
       }
-      e_lin += en - se * Tt;
-      if (Ql) e_q += sr * (double)qt;
+      if (DET) { ie_lin += det_fx(en - se * Tt, g.det_shr); if (Ql) ie_q += det_fx(sr * (double)qt, g.det_shr); }   // (per tie: the exact conversion, whatever the magnitude)
+      else { e_lin += en - se * Tt; if (Ql) e_q += sr * (double)qt; }
     }
     // Everything the NEXT step needs was requested at the top of this one: wait for it HERE, before the next step's own
     // requests go out.  (Left to itself the compiler waits at the first use, after those requests -- and where it cannot tell
@@ -668,16 +689,16 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     // deficits, plane 0); summed BEFORE the flush, whose float atomics the ticket below must not wait for
     double a0p = 0.0;
     for (int q = (tick[1] ? 0 : (int)hcm) + tid; q < nHc; q += nthr) {   // (plane 0 only when something was added to it)
-      const double v = Hc[q];
+      const double v = DET ? det_back(reinterpret_cast<const unsigned long long*>(Hc)[q], g.det_sh) : Hc[q];
       if (v != 0.0) {
         const int k = q / (int)hcm;
         const unsigned ym = (unsigned)(q - k * (int)hcm);
         a0p += ((k ? w2_at(ym, k) : 0.0) - w2_at(ym, 0)) * v;
       }
     }
-    a0p = block_sum_n(a0p, red);
+    a0p = block_sum_n(a0p, red);   // (a fixed thread <-> cell map and a fixed tree: the same double every run)
     if (tid == 0) {
-      if (a.det) atomicAdd(&det_R()[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
+      if (DET) atomicAdd(&det_R()[4], det_fx(a0p, g.det_sh)); else atomicAdd(&a.nu_acc[0], a0p);
     }
   }
 #ifdef SL_DEBUG
@@ -690,18 +711,24 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #endif
   if (a.do_hist && tid >= f0) {   // the LDS levels ([K][hc][Mp]) into this workgroup's copy of H ([Y][Mp][K])
     for (int q = (tick[1] ? 0 : (int)hcm) + tid - f0; q < nHc; q += nthr - f0) {
+      if (DET) {   // (the cell IS the fixed-point sum: added to the shadow as it stands)
+        const unsigned long long iv = reinterpret_cast<const unsigned long long*>(Hc)[q];
+        if (iv != 0ull) { const int k = q / (int)hcm, ym = q - k * (int)hcm; atomicAdd(&det_H()[(size_t)ym * K + k], iv); }
+        continue;
+      }
       const double v = Hc[q];
       if (v != 0.0) {
         const int k = q / (int)hcm, ym = q - k * (int)hcm;
-        if (a.det) atomicAdd(&det_H()[(size_t)ym * K + k], det_fx(v, g.det_sh)); else atomicAdd(&Hl[(size_t)ym * K + k], v);
+        atomicAdd(&Hl[(size_t)ym * K + k], v);
       }
     }
   }
   if (a.sum_a && tid >= f0) {   // this workgroup's mask-list sums into its slot of slotA ([l][slot][W*64][K])
     double* out = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
     for (int q = tid - f0; q < g.M * K; q += nthr - f0) {
+      if (DET) { const unsigned long long iv = reinterpret_cast<const unsigned long long*>(As)[q]; if (iv != 0ull) atomicAdd(&det_A()[q], iv); continue; }
       const double v = As[q];
-      if (v != 0.0) { if (a.det) atomicAdd(&det_A()[q], det_fx(v, DET_SH_A)); else atomicAdd(&out[q], v); }
+      if (v != 0.0) atomicAdd(&out[q], v);
     }
   }
 #ifdef SL_DEBUG
@@ -738,7 +765,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #pragma unroll
               for (int k = 1; k < K; ++k) vk[c][k - 1] = H0[(size_t)c * hcs + (size_t)it * K + k];
             }
-            if (a.det) {   // (deterministic mode: the far rows are in the integer shadow)
+            if (DET) {   // (deterministic mode: the far rows are in the integer shadow)
               const unsigned long long* hi = a.det + (size_t)ll * hcs + (size_t)it * K;
               v0[0] += det_back(hi[0], g.det_sh);
 #pragma unroll
@@ -772,7 +799,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       far = block_sum_n(far, red);
       if (tid == 0) {
         double tot = far;   // + every workgroup's share (device-scope read)
-        if (a.det) { unsigned long long* dR = det_R(); tot += det_back(atomicAdd(&dR[4], 0ull), g.det_sh); dR[4] = 0ull; } else tot += atomicAdd(&a.nu_acc[0], 0.0);
+        if (DET) { unsigned long long* dR = det_R(); tot += det_back(atomicAdd(&dR[4], 0ull), g.det_sh); dR[4] = 0ull; } else tot += atomicAdd(&a.nu_acc[0], 0.0);
         for (int ll = 0; ll < g.L; ++ll) tot += a.nu_acc[2 + ll];
         a.nu_acc[0] = 0.0; a.nu_acc[1] = 0.0;
         a.elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
@@ -786,21 +813,35 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       }
     }
   }
+  // a wave's integer sum (DET): 64-bit adds through two 32-bit shuffles
+  auto wave_isum = [&](unsigned long long v) SL_INL -> unsigned long long {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o2, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o2, 64);
+      v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+  };
   if ((UPDATE || (!ELBO && a.do_hist == 1)) && a.slotF) {   // (slotF null: a pass that only re-writes rho, ensure_rho)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+      if (DET) { const unsigned long long v = wave_isum(iaccF[k]); if (lane == 0 && v != 0ull) atomicAdd(&det_F()[k], v); continue; }
       double v = block_sum_n(accF[k], red);
-      if (tid == 0) { if (a.det) atomicAdd(&det_F()[k], det_fx(v, DET_SH_A)); else atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v); }
+      if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
     }
   }
   if (ELBO) {
-    double v1 = block_sum_n(e_lin, red);
-    double v2 = block_sum_n(e_log, red);
-    double v3 = block_sum_n(e_q, red);
-    if (tid == 0) {
-      double* out = a.slotR + (size_t)(bx % NSLOT) * 4;
-      if (a.det) { unsigned long long* dR = det_R(); atomicAdd(&dR[1], det_fx(v1, g.det_shr)); atomicAdd(&dR[2], det_fx(v2, g.det_shr)); atomicAdd(&dR[3], det_fx(v3, g.det_shr)); }
-      else { atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3); }
+    if (DET) {
+      const unsigned long long v1 = wave_isum(ie_lin), v2 = wave_isum(ie_log), v3 = wave_isum(ie_q);
+      if (lane == 0) { unsigned long long* dR = det_R(); atomicAdd(&dR[1], v1); atomicAdd(&dR[2], v2); atomicAdd(&dR[3], v3); }
+    } else {
+      double v1 = block_sum_n(e_lin, red);
+      double v2 = block_sum_n(e_log, red);
+      double v3 = block_sum_n(e_q, red);
+      if (tid == 0) {
+        double* out = a.slotR + (size_t)(bx % NSLOT) * 4;
+        atomicAdd(&out[1], v1); atomicAdd(&out[2], v2); atomicAdd(&out[3], v3);
+      }
     }
   }
 #ifdef SL_DEBUG
@@ -810,9 +851,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 
 #define SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) \
   __launch_bounds__(sl_tpb_max(K, ELBO, ALLFULL, UPDATE), (K == 2 && !ELBO && ALLFULL) ? SL_WPE : sl_wpe(K, ELBO, ALLFULL, UPDATE))
-template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
+template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true, bool DET = false>
 __global__ SL_BOUNDS(K, UPDATE, ELBO, ALLFULL) void k_sweep_sl(SlArgs a, Geo g) {
-  sweep_body<K, UPDATE, ELBO, ALLFULL, STORE>(a, g, blockIdx.x, gridDim.x);
+  sweep_body<K, UPDATE, ELBO, ALLFULL, STORE, DET>(a, g, blockIdx.x, gridDim.x);
 }
 // One launch for many small handles in lockstep (vmr_fit_loop_batch): workgroup -> unit through `blk_unit`, the unit's
 // arguments from device memory.  A sweep of a Karnataka-sized layer is two dependent 20-40 us launches that leave the GPU
@@ -826,12 +867,12 @@ __global__ __launch_bounds__(sl_tpb_max_b(K, ELBO, ALLFULL), sl_wpe_b(K, ELBO, A
 // ------------------------------------------------------------------------------------------
 // launcher of this object's K
 // ------------------------------------------------------------------------------------------
-template <bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true>
+template <bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true, bool DET = false>
 static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
   constexpr int K = VMR_K;
   const Geo& g = h->g;
   const long long NS = ((long long)g.N * g.N + 63) / 64, nw = sh.tpb / 64;
-  int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
+  int rc = grid_per_layer(h, k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE, DET>, sh.smem, &a.Gl, (NS + nw - 1) / nw, sh.tpb);
   if (rc) return rc;
 #ifdef SL_DEBUG
   // VMR_DEBUG_TIMES=<file>: every launch appends "<update><elbo> <waves>" and one line of four clock readings per wave
@@ -844,7 +885,7 @@ static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
     if (nwv * 64 <= ((size_t)1 << 22)) a.dbg_t = dbg_buf;
   }
 #endif
-  hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
+  hipLaunchKernelGGL((k_sweep_sl<K, UPDATE, ELBO, ALLFULL, STORE, DET>), dim3(g.L * a.Gl), dim3(sh.tpb), sh.smem, h->stream, a, g);
 #ifdef SL_DEBUG
   if (a.dbg_t) {
     std::vector<unsigned long long> t(nwv * 8);
@@ -863,6 +904,24 @@ static int sl_launch_one(vmr_ctx* h, const SlShape& sh, SlArgs& a) {
 #define SL_CAT2(a, b) a##b
 #define SL_CAT(a, b) SL_CAT2(a, b)
 int SL_CAT(vmr_sl_launch_k, VMR_K)(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
+  if (a.det) {   // deterministic mode: the integer-sum variants
+    if (a.cls == nullptr) {
+      switch (mode) {
+        case 0: return sl_launch_one<true, false, true, true, true>(h, sh, a);
+        case 4: return sl_launch_one<true, false, true, false, true>(h, sh, a);
+        case 1: return sl_launch_one<true, true, true, true, true>(h, sh, a);
+        case 2: return sl_launch_one<false, true, true, true, true>(h, sh, a);
+        default: return sl_launch_one<false, false, true, true, true>(h, sh, a);
+      }
+    }
+    switch (mode) {
+      case 0: return sl_launch_one<true, false, false, true, true>(h, sh, a);
+      case 4: return sl_launch_one<true, false, false, false, true>(h, sh, a);
+      case 1: return sl_launch_one<true, true, false, true, true>(h, sh, a);
+      case 2: return sl_launch_one<false, true, false, true, true>(h, sh, a);
+      default: return sl_launch_one<false, false, false, true, true>(h, sh, a);
+    }
+  }
   if (a.cls == nullptr) {   // every mask row is all ones
     switch (mode) {
       case 0: return sl_launch_one<true, false, true>(h, sh, a);

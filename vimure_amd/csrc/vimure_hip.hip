@@ -1740,7 +1740,6 @@ static size_t shmem_rho(const Geo& g, bool update, bool elbo) {
 static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
   const Geo& g = h->g;
   SlShape s{std::max(64, std::min((update || elbo) ? h->sp_tpb : h->st_tpb, sl_tpb_max(g.K, elbo, h->all_full != 0, update)) & ~63), update ? g.yt : 0, hist ? g.hc : 0, 0};
-  if (g.det) s.tpb = 64;   // deterministic mode: a workgroup is one wave (its LDS adds then happen in program order)
   auto bytes = [&]() { return sl_smem(g, s.yt, s.hc, update, elbo, hist); };
   while (bytes() > SP_LDS_MAX && (s.yt > 0 || s.hc > 0)) { if (s.yt >= s.hc && s.yt > 0) --s.yt; else --s.hc; }
   s.smem = bytes();
@@ -2010,7 +2009,7 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false,
     // the rho of a sweep that the next one overwrites unread is not written: only with mutuality's nu committed inside the pass
     // (the re-write of ensure_rho takes the nu before that commit from SC_G_NU_STALE) or without mutuality, in one pass per sweep
     // -- and only where the pass itself sums rho over the mask rows: the mask kernels of launch_gamma read rho from memory
-    const bool lazy = !store && mode == 0 && do_hist && !g.det && (nu_in_pass ? commit_nu : !g.mut) && g.fuse_full && (h->n_partial == 0 || g.ml) &&
+    const bool lazy = !store && mode == 0 && do_hist && (nu_in_pass ? commit_nu : !g.mut) && g.fuse_full && (h->n_partial == 0 || g.ml) &&
                       !getenv("VMR_ALWAYS_STORE_RHO");
     if ((rc = sl_launch(h, lazy ? 4 : mode, shs, as))) return rc;
     if (mode != 2) h->rho_stale = lazy;
@@ -2414,11 +2413,11 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     CK(hipStreamSynchronize(h->stream));
     int bits = 1;
     while (bits < 62 && (sx >> bits) != 0ull) ++bits;
-    g.det_sh = std::max(0, 61 - bits);
+    g.det_sh = std::min(40, std::max(0, 61 - bits));    // (<= 40: the conversion trick of the sweep kernel holds |v| 2^sh < 2^51, v up to 2047)
     const unsigned long long eb = 64ull * (sx + (unsigned long long)L * g.N * g.N * K);
     int rbits = 1;
     while (rbits < 62 && (eb >> rbits) != 0ull) ++rbits;
-    g.det_shr = std::max(0, 61 - rbits);
+    g.det_shr = std::min(34, std::max(0, 61 - rbits));   // (<= 34: ELBO terms up to 2047 * |log eps| < 2^17)
     const size_t nd = (size_t)L * g.Y * g.Mp * K + (size_t)L * g.W * 64 * K + (size_t)L * K + 5;
     CK(hipMalloc(&h->det_buf, nd * 8));
     CK(hipMemsetAsync(h->det_buf, 0, nd * 8, h->stream));
