@@ -247,7 +247,10 @@ def main():
                                            "collected in separate --pmc passes; not re-measured in this run)",
                          "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": d["bytes_per_launch"],
-                         "byte_model": ("report lists: 4 B x nnz(X) + 4 B x ties + log-prior read + rho write"
+                         "byte_model": ("report lists: 4 B x nnz(X) + 4 B per 64 ties + log-prior read; rho is used (statistics, nu) and NOT "
+                                        "written: the next sweep overwrites it unread (the last sweep of a vmr_step call and ELBO sweeps write it)"
+                                        if dom == "rho_nostore" else
+                                        "report lists: 4 B x nnz(X) + 4 B per 64 ties + log-prior read + rho write"
                                         if fmt == "sparse" else "dense: X 1 B/elt + R 1 bit/elt + log-prior read + rho write")},
             "kernels": {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches": v["launches"],
                             "GBps": (v["bytes_per_launch"] / (v["ms"] / max(1, v["launches"]) * 1e-3) / 1e9)
@@ -579,10 +582,16 @@ def cpu_baseline_sparse(cfg, net, host, pr, budget_s, parity):
     import torch
     from oracle import cavi_coo
     L, N, M, K = cfg["L"], cfg["N"], cfg["M"], cfg["K"]
-    idx = torch.nonzero(net.X)
-    vals = net.X[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]].cpu().numpy().astype(np.int32)
-    subs = tuple(idx[:, d].cpu().numpy() for d in range(4))
-    del idx
+    parts, vparts = [], []
+    for l in range(L):   # (layer by layer: torch.nonzero fails beyond 2^31 elements)
+        il = torch.nonzero(net.X[l])
+        vparts.append(net.X[l][il[:, 0], il[:, 1], il[:, 2]].cpu().numpy().astype(np.int32))
+        parts.append(np.concatenate([np.full((il.shape[0], 1), l, np.int64), il.cpu().numpy()], axis=1))
+        del il
+    idx = np.concatenate(parts, axis=0)
+    vals = np.concatenate(vparts)
+    subs = tuple(np.ascontiguousarray(idx[:, d]) for d in range(4))
+    del idx, parts, vparts
     t0 = time.perf_counter()
     c = cavi_coo.CooRef((subs, vals), None, (L, N, N, M), K, cfg["mutuality"], (0.1, 0.1, 10.0, 10.0, 0.5, 1.0),
                         host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)

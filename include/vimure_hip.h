@@ -51,7 +51,9 @@ enum {
   VMR_KERNEL_ELBO = 4,         /* stand-alone ELBO sweep                                      */
   VMR_KERNEL_FINALIZE = 5,     /* the small reduce/parameter kernels                          */
   VMR_KERNEL_RHO_ELBO = 6,     /* rho update with the ELBO data terms reduced in the same pass */
-  VMR_KERNEL_COUNT = 7
+  VMR_KERNEL_RHO_NOSTORE = 7,  /* rho update whose rho is used (statistics, nu) but not written: the inner sweeps of a vmr_step call, whose rho
+                                  the next sweep overwrites unread */
+  VMR_KERNEL_COUNT = 8
 };
 
 /*

@@ -80,6 +80,8 @@ def main():
                     o = 1 if "k_sweep_sl" in name else 2
                     upd, elbo = flags[o] == "true", flags[o + 1] == "true"
                     cls = "rho_elbo" if (upd and elbo) else ("rho" if upd else ("elbo" if elbo else "gamma_counts"))
+                    if cls == "rho" and "k_sweep_sl" in name and len(flags) > o + 3 and flags[o + 3] == "false":
+                        cls = "rho_nostore"   # <K, UPDATE, ELBO, ALLFULL, STORE, DET>: rho used, not written
                 if cls:
                     traffic[cls] = rd + wb
         pj = os.path.join(dst, "pmc_traffic.json")

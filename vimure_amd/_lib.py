@@ -10,9 +10,9 @@ LIB_PATH = os.environ.get("VMR_LIB", os.path.join(HERE, "libvimure_hip.so"))  # 
 
 VMR_OK, VMR_EINVAL, VMR_EHIP, VMR_ENAN, VMR_ESTATE = 0, -1, -2, -3, -4
 STEP_GAMMA, STEP_PHI, STEP_RHO, STEP_NU = 0, 1, 2, 3
-KERNEL_GAMMA_MASK, KERNEL_GAMMA_COUNTS, KERNEL_PHI, KERNEL_RHO, KERNEL_ELBO, KERNEL_FINALIZE, KERNEL_RHO_ELBO = range(7)
+KERNEL_GAMMA_MASK, KERNEL_GAMMA_COUNTS, KERNEL_PHI, KERNEL_RHO, KERNEL_ELBO, KERNEL_FINALIZE, KERNEL_RHO_ELBO, KERNEL_RHO_NOSTORE = range(8)
 READ_RHO_MAX, READ_RHO_MEAN, READ_THRESHOLD = 0, 1, 2
-KERNEL_NAMES = ["gamma_mask", "gamma_counts", "phi", "rho", "elbo", "finalize", "rho_elbo"]
+KERNEL_NAMES = ["gamma_mask", "gamma_counts", "phi", "rho", "elbo", "finalize", "rho_elbo", "rho_nostore"]
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.c_void_p  # host or device pointer

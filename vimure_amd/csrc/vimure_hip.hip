@@ -1997,7 +1997,6 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false,
   const bool nu_in_pass = h->sparse && g.mut && mode != 2 && (commit_nu || raw_nu);
   if (mode == 2 && (rc = ensure_rho(h))) return rc;
   if (h->sparse) {
-    Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
     const int do_hist = (mode != 2 && !g.two_pass) ? 1 : 0;
     const int sum_a = (g.ml && do_hist) ? 1 : 0;   // (two passes: the statistics pass that follows sums the lists)
     if (mode != 2) h->a_valid = false;
@@ -2011,7 +2010,10 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false,
     // -- and only where the pass itself sums rho over the mask rows: the mask kernels of launch_gamma read rho from memory
     const bool lazy = !store && mode == 0 && do_hist && (nu_in_pass ? commit_nu : !g.mut) && g.fuse_full && (h->n_partial == 0 || g.ml) &&
                       !getenv("VMR_ALWAYS_STORE_RHO");
-    if ((rc = sl_launch(h, lazy ? 4 : mode, shs, as))) return rc;
+    {
+      Prof p(h, lazy ? VMR_KERNEL_RHO_NOSTORE : mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
+      if ((rc = sl_launch(h, lazy ? 4 : mode, shs, as))) return rc;
+    }
     if (mode != 2) h->rho_stale = lazy;
     if ((rc = det_fold(h))) return rc;
   } else {
@@ -3611,7 +3613,7 @@ int vmr_profile(vmr_handle h, int enable) {
   h->prof = enable != 0;
   // enable = 2: only the passes over the data (the roofline kernels); the small finalize kernels run unbracketed -- two event
   // records per launch are ~4 us on the stream, 9 % of a config-3 sweep when every kernel carries them
-  h->prof_mask = enable == 2 ? ((1u << VMR_KERNEL_GAMMA_COUNTS) | (1u << VMR_KERNEL_RHO) | (1u << VMR_KERNEL_ELBO) | (1u << VMR_KERNEL_RHO_ELBO)) : ~0u;
+  h->prof_mask = enable == 2 ? ((1u << VMR_KERNEL_GAMMA_COUNTS) | (1u << VMR_KERNEL_RHO) | (1u << VMR_KERNEL_ELBO) | (1u << VMR_KERNEL_RHO_ELBO) | (1u << VMR_KERNEL_RHO_NOSTORE)) : ~0u;
   if (enable) { memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n); }
   return VMR_OK;
 }
@@ -3655,6 +3657,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
       case VMR_KERNEL_GAMMA_MASK: *bytes = ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0) + Srho; break;
       case VMR_KERNEL_GAMMA_COUNTS: *bytes = E + RP + Srho; break;
       case VMR_KERNEL_RHO: *bytes = E + RP + mask + 2.0 * Srho; break;
+      case VMR_KERNEL_RHO_NOSTORE: *bytes = E + RP + mask + Srho; break;   // (the log prior is read, rho is not written)
       case VMR_KERNEL_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;
       case VMR_KERNEL_RHO_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;
       default: *bytes = 0.0; break;
