@@ -282,8 +282,8 @@ def test_rho_of_inner_sweeps_is_not_written_and_nothing_can_tell(mask, monkeypat
     monkeypatch.setenv("VMR_DEBUG_LAZY_RHO", "1")
     c = run("one call")
     for other in (b, c):
-        np.testing.assert_allclose(other[0], a[0], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(other[0], a[0], rtol=1e-9, atol=1e-13)
         for k in ("rho", "gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp"):
-            np.testing.assert_allclose(other[1][k], a[1][k], rtol=1e-11, atol=1e-14, err_msg=k)
-        assert abs(other[2] - a[2]) <= 1e-11 * abs(a[2])
-        np.testing.assert_allclose(other[3], a[1]["rho"], rtol=1e-11, atol=1e-14)
+            np.testing.assert_allclose(other[1][k], a[1][k], rtol=1e-9, atol=1e-13, err_msg=k)
+        assert abs(other[2] - a[2]) <= 1e-10 * abs(a[2])
+        np.testing.assert_allclose(other[3], a[1]["rho"], rtol=1e-9, atol=1e-13)

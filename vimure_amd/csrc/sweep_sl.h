@@ -64,6 +64,9 @@ struct SlArgs {
   // partials | 1 nu share -- which k_det_fold turns into the doubles the finalize kernels read.  Inside a workgroup nothing
   // needs it: a workgroup is ONE wave there and walks a fixed share of the steps in order.  null: floating-point atomics.
   unsigned long long* det;
+  // Every tie of a step WITHOUT reports carries the reference's one-hot prior (1, 0, .., 0) (model.py:536-556; found at vmr_set_state):
+  // such steps -- 99.99 % of a survey layer's -- take log(1 + eps), log(eps) from registers instead of 8 K bytes per tie from memory.
+  int lp0;
 #ifdef SL_DEBUG
   unsigned long long* dbg_t;   // [waves][8]: a wave's start, end of prologue, end of step loop, end; first loads issued, tables' barrier, nu share done, flush done (100 MHz clock)
 #endif

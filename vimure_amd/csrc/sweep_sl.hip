@@ -127,6 +127,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(p), fxm(v, scale)); else atomicAdd(p, v);
   };
   const float rcp_mp = 1.0f / (float)Mp;
+  const double lp0_0 = log(1.0 + eps), lp0_k = log(eps);   // the log prior of a tie nobody reported on (the values k_init_rho_pos stored)
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K];
 #pragma unroll
@@ -190,7 +191,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   };
   // loads of one step's per-tie values: a scalar base per step plus a constant per-lane offset, no masks (the arrays carry
   // 64 rows of slack; positions past the last tie read them and are switched off through `cls`) ...
-  auto fetch_tie = [&](StepIn<K>& d, long long st) SL_INL {
+  auto fetch_tie = [&](StepIn<K>& d, long long st, const bool lp_const = false) SL_INL {   // lp_const: the step's log prior is the one-hot one (SlArgs::lp0)
     const size_t row0 = (size_t)st * 64;
     const bool ok = (unsigned)row0 + (unsigned)lane < T32;
     d.qt = 0u; d.tie = 0u;
@@ -203,7 +204,12 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     if (ELBO && Ql) d.qt = *at_bytes(Ql + row0, lane4);
 #pragma unroll
     for (int k = 0; k < K; ++k) { d.v[k] = 0.0; d.w[k] = 0.0; }
-    if (UPDATE || ELBO) load_k<K>(at_bytes(lpl + row0 * K, laneK8), d.v);
+    if (UPDATE || ELBO) {
+      if (lp_const) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) d.v[k] = k == 0 ? lp0_0 : lp0_k;
+      } else load_k<K>(at_bytes(lpl + row0 * K, laneK8), d.v);
+    }
     if (!UPDATE && a.do_hist != 2) load_k<K>(at_bytes(static_cast<const double*>(rl) + row0 * K, laneK8), d.w);
   };
   // ... and of its first CNT rounds (rounds it does not have read later steps' slots, unused; in bounds: SL_SLACK)
@@ -403,35 +409,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     lds_add(&Hc[SL_YM(ent)], (double)SL_X(ent) * dfc, sc_h);
   };
   // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
-  auto body = [&](auto rct) SL_INL {
+  // ---- the work of one step on its loaded values: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general
+  // (far levels, or more rounds).  row0 / act: the step's first position, this lane's tie exists; ea_c, Rr: its slots and rounds.
+  auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned ymax) SL_INL {
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
-    const size_t row0 = (size_t)s * 64;
-    const bool act = (unsigned)row0 + (unsigned)lane < T32;
-    const unsigned ea_c = ea;
-    const int Rr = RCT < 0 ? R : RCT;
-    const StepIn<K> cur = P;
-    // the next step: its range was loaded a step ago; its per-tie values and rounds now.  It has at most as many rounds as
-    // this one (sorted order), so NP loads cover them; surplus loads read later steps' slots, unused.  After the wave's last
-    // step the same loads are issued once more, of this step's own (valid) addresses: no branch around a load.
-    const long long s2 = sn, s3 = draw();
-    const bool more = s2 < NS;
-    const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
-    const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
-    const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
-    fetch_range(s3 < NS ? s3 : s);
-    fetch_tie(P, more ? s2 : s);
-    if (RCT >= 0 || PFK <= 8) fetch_ent(P, ea2, RC<NP>{});
-    else {   // a general step of a wide-prefetch variant: as many blocks of 8 rounds as the next step has
-      const unsigned* pe = El + ea2;
-#pragma unroll
-      for (int j0 = 0; j0 < PFK; j0 += 8) {
-        if (j0 == 0 || j0 < R2) {   // (wave-uniform)
-#pragma unroll
-          for (int j = j0; j < j0 + 8; ++j) P.e[j] = *at_bytes(pe + j * 64, lane4);
-        }
-      }
-    }
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
     // The rounds of a general step, ONE loop for all of them so that the per-round code exists PFK times and no more (a
     // body of tens of kilobytes does not stay in the instruction cache: a cut with the prefetched rounds and the ring walked
@@ -646,6 +628,38 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (DET) { ie_lin += det_fx(en - se * Tt, g.det_shr); if (Ql) ie_q += det_fx(sr * (double)qt, g.det_shr); }   // (per tie: the exact conversion, whatever the magnitude)
       else { e_lin += en - se * Tt; if (Ql) e_q += sr * (double)qt; }
     }
+  };
+  // ---- one step: prefetch of the next, the work (compute), one wait
+  auto body = [&](auto rct) SL_INL {
+    constexpr int RCT = decltype(rct)::value;
+    constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
+    const size_t row0 = (size_t)s * 64;
+    const bool act = (unsigned)row0 + (unsigned)lane < T32;
+    const unsigned ea_c = ea;
+    const int Rr = RCT < 0 ? R : RCT;
+    const StepIn<K> cur = P;
+    // the next step: its range was loaded a step ago; its per-tie values and rounds now.  It has at most as many rounds as
+    // this one (sorted order), so NP loads cover them; surplus loads read later steps' slots, unused.  After the wave's last
+    // step the same loads are issued once more, of this step's own (valid) addresses: no branch around a load.
+    const long long s2 = sn, s3 = draw();
+    const bool more = s2 < NS;
+    const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
+    const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
+    const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
+    fetch_range(s3 < NS ? s3 : s);
+    fetch_tie(P, more ? s2 : s, RCT == 0 && a.lp0 != 0);   // (sorted order: after a step without reports come only such steps)
+    if (RCT >= 0 || PFK <= 8) fetch_ent(P, ea2, RC<NP>{});
+    else {   // a general step of a wide-prefetch variant: as many blocks of 8 rounds as the next step has
+      const unsigned* pe = El + ea2;
+#pragma unroll
+      for (int j0 = 0; j0 < PFK; j0 += 8) {
+        if (j0 == 0 || j0 < R2) {   // (wave-uniform)
+#pragma unroll
+          for (int j = j0; j < j0 + 8; ++j) P.e[j] = *at_bytes(pe + j * 64, lane4);
+        }
+      }
+    }
+    compute(rct, cur, row0, act, ea_c, Rr, ymax);
     // Everything the NEXT step needs was requested at the top of this one: wait for it HERE, before the next step's own
     // requests go out.  (Left to itself the compiler waits at the first use, after those requests -- and where it cannot tell
     // how many requests are younger than the ones it needs it drains them all: memory latency in every step.)  This step's rho

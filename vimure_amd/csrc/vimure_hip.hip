@@ -416,15 +416,23 @@ __global__ void k_init_rho(const double* __restrict__ pr, double* __restrict__ r
 }
 
 // the same for a handle whose rho / log prior live in sorted position order (sweep_sl.h): pr is in tie order
+// (rs / not_onehot: does every tie of a step WITHOUT reports carry the one-hot prior (1, 0, .., 0) the reference gives ties nobody
+// reported on (model.py:536-556)?  Then the sweeps need not read the log prior of those steps -- SlArgs::lp0)
 __global__ void k_init_rho_pos(const double* __restrict__ pr, double* __restrict__ rho, double* __restrict__ logpr,
-                               const unsigned* __restrict__ perm, size_t T, size_t NS, int L, int K, double eps) {
+                               const unsigned* __restrict__ perm, size_t T, size_t NS, int L, int K, double eps,
+                               const unsigned* __restrict__ rs, int* __restrict__ not_onehot) {
   const size_t n = (size_t)L * T * K;
+  bool bad = false;
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
     const size_t row = q / K, k = q - row * K, l = row / T, pos = row - l * T;
     const double v = pr[(l * T + perm[l * NS * 64 + pos]) * K + k];
     rho[q] = v;
     logpr[q] = log(v + eps);
+    const unsigned* rsl = rs + l * (NS + 1);
+    const size_t st = pos >> 6;
+    if (rsl[st + 1] == rsl[st] && v != (k == 0 ? 1.0 : 0.0)) bad = true;
   }
+  if (bad) atomicOr(not_onehot, 1);
 }
 
 // nibble LUT of E[theta] for wide masks: lut[l][n][e] = sum of E[theta_m] over the set bits e of reporters 4n..4n+3
@@ -1747,7 +1755,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0};
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0};
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -2967,7 +2975,14 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
       src = h->nat;
     }
     const size_t T_ = (size_t)g.N * g.N;
-    hipLaunchKernelGGL(k_init_rho_pos, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, h->perm, T_, (T_ + 63) / 64, g.L, g.K, g.eps);
+    int* flag = reinterpret_cast<int*>(h->elbo_dev + 7);   // (the spare double of the ELBO scratch)
+    HIPCHK(h, hipMemsetAsync(flag, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_init_rho_pos, dim3(4096), dim3(256), 0, h->stream, src, h->rho, h->logpr, h->perm, T_, (T_ + 63) / 64, g.L, g.K, g.eps,
+                       h->rs, flag);
+    int nf = 1;
+    HIPCHK(h, hipMemcpyAsync(&nf, flag, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->lp0 = nf == 0 && !getenv("VMR_NO_LP0");
   } else {
     if (!pr_rho_on_device) {
       // stage through logpr (overwritten by k_init_rho element-wise after being read)

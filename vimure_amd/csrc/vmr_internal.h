@@ -128,6 +128,7 @@ struct vmr_ctx {
   double* fr_slots = nullptr;              // ... and k_fin_rho's per-workgroup partial sums [L * FR_G][2]
   double *rho_snap = nullptr, *par_snap = nullptr;   // vmr_snapshot: the best realisation so far (model.py:925-942)
   bool have_snap = false;
+  bool lp0 = false;            // every tie of a step without reports carries the one-hot prior: the sweeps do not read those steps' log prior (SlArgs::lp0)
   bool rho_stale = false;      // the last sweep used its new rho without writing it (sweep_body's STORE = false): ensure_rho re-writes it before anyone reads
   bool restored = false;       // vmr_restore brought back rho and the parameters of another realisation, not its log prior: no sweeps until vmr_set_state
   size_t par_doubles = 0;
