@@ -1355,12 +1355,14 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
     const double pa_th = par[o.a_th + q], pb_th = par[o.b_th + q];
     for (int k = 0; k < K; ++k) {
       double av[NSLOT], ak = 0.0;
+      if (slotA) {   // (null: the mask has no partial rows, nothing ever lands in the slots -- a memory round trip less)
 #pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) av[sl] = slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];   // loads first
+        for (int sl = 0; sl < NSLOT; ++sl) av[sl] = slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k];   // loads first
 #pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) {
-        ak += av[sl];
-        slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k] = 0.0;   // consume: the slots are zero again for the next sweep
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          ak += av[sl];
+          slotA[(((size_t)l * NSLOT + sl) * Wp + m) * K + k] = 0.0;   // consume: the slots are zero again for the next sweep
+        }
       }
       ak += fk[k];
       A[k] = ak;
@@ -1414,12 +1416,15 @@ __device__ __forceinline__ void fin_gamma_body(double* par, double* Hg, const do
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const double t = atomicAdd(&finl[2 * KMAX], 1.0);
-    last = (t == (double)(fg - 1));
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fg == 1) last = 1;   // (one workgroup has the whole layer: nothing to publish, no ticket, no fences)
+    else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const double t = atomicAdd(&finl[2 * KMAX], 1.0);
+      last = (t == (double)(fg - 1));
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
   if (!last) return;
@@ -1962,7 +1967,8 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     const int consume = (with_phi && !g.two_pass) ? 1 : 0;
     const int nh = h->h_reduced ? 1 : NH;
     const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
-    hipLaunchKernelGGL(g.det ? k_fin_gamma_det : k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr, h->slotA,
+    hipLaunchKernelGGL(g.det ? k_fin_gamma_det : k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr,
+                       (h->all_full && h->n_partial == 0) ? nullptr : h->slotA,
                        h->slotF, h->lutg, nullptr, h->fin_g, h->sparse ? h->nu_acc : nullptr, nh,
                        with_phi ? 1 : 0, consume, g);
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
@@ -3203,6 +3209,7 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
     long long layers = 0;
     for (int u : act) layers += hs[u]->g.L;
     bt.fg = (int)std::max<long long>(2, std::min<long long>(FG_G, (2LL * h0->ncu) / std::max<long long>(1, layers)));
+    if (getenv("VMR_BATCH_FG")) bt.fg = std::max(1, std::min(FG_G, atoi(getenv("VMR_BATCH_FG"))));   // (experiments)
   }
   for (size_t i = 0; i < act.size(); ++i) {
     vmr_ctx* h = hs[act[i]];
