@@ -29,14 +29,17 @@ def rows(k, text):
     out = []
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", text, re.S):
         name, blk = m.group(1), m.group(2)
-        t = re.search(r"k_sweep_sl(_b)?ILi(\d+)ELb([01])ELb([01])ELb([01])E", name)
+        t = re.search(r"k_sweep_sl(_b)?ILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])(?:ELb([01]))?E", name)
         if not t:
             continue
         lock = t.group(1) is not None
-        t = re.search(r"ILi(\d+)ELb([01])ELb([01])ELb([01])E", name)
         g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))
-        upd, elbo, full = t.group(2) == "1", t.group(3) == "1", t.group(4) == "1"
+        upd, elbo, full, store, det = t.group(3) == "1", t.group(4) == "1", t.group(5) == "1", t.group(6) == "1", t.group(7) == "1"
         variant = ("update+ELBO" if elbo else "update") if upd else ("ELBO only" if elbo else "statistics only")
+        if not store:
+            variant += ", rho not written"
+        if det:
+            variant += ", deterministic"
         if lock:
             variant += " (lockstep)"
         vg = g("vgpr_count")
@@ -54,7 +57,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp, ThreadPoolExecutor(max_workers=min(len(a.k), os.cpu_count() or 1)) as ex:
         texts = list(ex.map(lambda k: asm_for(k, tmp), a.k))
     table = [r for k, t in zip(a.k, texts) for r in sorted(rows(k, t), key=lambda r: (r[1], r[2]))]
-    lines = ["# k_sweep_sl / k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL>: registers and scratch per variant (code-object metadata, gfx950)", "",
+    lines = ["# k_sweep_sl / k_sweep_sl_b<K, UPDATE, ELBO, ALLFULL, STORE, DET>: registers and scratch per variant (code-object metadata, gfx950)", "",
              "SGPR spills go to VGPR lanes (v_writelane), not to memory; `VGPR spills` and `scratch` are what costs.", "",
              "| K | variant | mask rows | VGPRs | waves/SIMD by VGPRs | SGPRs | VGPR spills | SGPR spills | scratch B/lane |", "|---|---|---|---|---|---|---|---|---|"]
     lines += ["| " + " | ".join(str(v) for v in r) + " |" for r in table]
