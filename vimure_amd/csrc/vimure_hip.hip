@@ -3182,7 +3182,26 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
     // costs a workgroup's fixed part -- its tables, its share of nu: some ten steps' worth -- again), at least 4 steps each, at
     // most 64 (192 fits of N = 200..800, lockstep loops: cap 8 1.05 s, 16 0.88, 32 0.78, 64 0.72, none 0.96 -- a small unit
     // then is one workgroup that walks all its steps)
-    const long long per = std::max<long long>(4, std::min<long long>(per_cap, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
+    long long per = std::max<long long>(4, std::min<long long>(per_cap, (steps + (long long)nw * h0->ncu - 1) / ((long long)nw * h0->ncu)));
+    {
+      // ... but never a FEW workgroups more than are resident at once: every workgroup of the launch gets the largest unit's LDS
+      // (a village of N = 900: 130 KB, one workgroup per CU), and with 293 workgroups on 256 CUs the launch takes two rounds for
+      // the sake of 37.  Then rather more steps per wave, until one round holds them all.
+      size_t smem_max = 0;
+      for (int u : act) smem_max = std::max(smem_max, sl_shape(hs[u], m != 2, m == 1, true).smem);
+      const int wpc = std::max<int>(1, std::min<int>((int)(SP_LDS_MAX / std::max<size_t>(smem_max, 1)), 4 * sl_wpe_b(K, m == 1, allfull) / nw));
+      const long long cap_wgs = (long long)h0->ncu * wpc;
+      auto total = [&](long long p_) {
+        long long t = 0;
+        for (int u : act) { const Geo& g = hs[u]->g; const long long NS = ((long long)g.N * g.N + 63) / 64; t += (long long)g.L * ((NS + nw * p_ - 1) / (nw * p_)); }
+        return t;
+      };
+      if (total(per) > cap_wgs && !getenv("VMR_BATCH_PER")) {
+        long long p2 = per;
+        while (p2 < 512 && total(p2) > cap_wgs) p2 += std::max<long long>(1, p2 / 16);
+        if (total(p2) <= cap_wgs) per = p2;
+      }
+    }
     std::vector<SlUnit> su(act.size());
     std::vector<int> map;
     size_t smem = 0;
@@ -3205,10 +3224,10 @@ static int batch_tables(vmr_ctx* const* hs, const std::vector<int>& act, int n_a
     bt.nb[m] = (int)map.size(); bt.tpb[m] = tpb; bt.smem[m] = smem;
   }
   bt.fsm = 0;
-  {   // workgroups per layer of the finalize launch: about two per CU in all, 2..FG_G per layer
+  {   // workgroups per layer of the finalize launch: about one per CU in all, 2..FG_G per layer
     long long layers = 0;
     for (int u : act) layers += hs[u]->g.L;
-    bt.fg = (int)std::max<long long>(2, std::min<long long>(FG_G, (2LL * h0->ncu) / std::max<long long>(1, layers)));
+    bt.fg = (int)std::max<long long>(2, std::min<long long>(FG_G, (1LL * h0->ncu) / std::max<long long>(1, layers)));   // (64 units: 4 -- measured 1 / 2 / 4 / 8 / 16: 3.29 / 3.06 / 2.95 / 3.11 / 3.33 s of loops)
     if (getenv("VMR_BATCH_FG")) bt.fg = std::max(1, std::min(FG_G, atoi(getenv("VMR_BATCH_FG"))));   // (experiments)
   }
   for (size_t i = 0; i < act.size(); ++i) {
