@@ -23,6 +23,7 @@ struct GenArgs {
   double* rho; const double* logpr; const double* par;
   double *slotR, *Hg, *slotF, *slotA;
   int Gl, update, elbo, hist, sum_a;
+  int lds_tab;   // the per-reporter tables (G_theta, E log theta, E theta: 24 Mp bytes) are copied to LDS
 };
 
 template <int NCH>
@@ -37,9 +38,15 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
   const ParOff o = par_off(g.L, Mp, K);
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);
+  extern __shared__ double gen_lds[];
   const double* Gth = a.par + o.G_th + (size_t)l * Mp;
   const double* Lth = a.par + o.l_th + (size_t)l * Mp;
   const double* Eth = a.par + o.E_th + (size_t)l * Mp;
+  if (a.lds_tab) {   // (a report's factor is computed where it is used: two table reads per report, from LDS instead of L2)
+    for (int m = tid; m < Mp; m += (int)blockDim.x) { gen_lds[m] = Gth[m]; gen_lds[Mp + m] = Lth[m]; gen_lds[2 * Mp + m] = Eth[m]; }
+    __syncthreads();
+    Gth = gen_lds; Lth = gen_lds + Mp; Eth = gen_lds + 2 * Mp;
+  }
   {   // T of an all-ones mask row: sum_m E[theta_m] (model.py:766-792)
     double tf = 0.0;
     for (int m = tid; m < g.M; m += (int)blockDim.x) tf += Eth[m];
@@ -381,12 +388,15 @@ static int gen_pass(vmr_ctx* h, int update, int elbo, int hist, int sum_a) {
   const Geo& g = h->g;
   const long long NS = ((long long)g.N * g.N + 63) / 64;
   GenArgs a{h->E, h->EX, h->rs, h->ebase, h->perm, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rho, h->logpr, h->par,
-            h->slotR, h->Hg, h->slotF, h->slotA, 1, update, elbo, hist, sum_a};
+            h->slotR, h->Hg, h->slotF, h->slotA, 1, update, elbo, hist, sum_a, 0};
   a.Gl = (int)std::max<long long>(1, std::min<long long>((NS + 3) / 4, std::max<long long>(1, (long long)h->ncu * 8 / g.L)));
   const dim3 grid((unsigned)(g.L * a.Gl)), blk(256);
-  if (g.K <= 64) hipLaunchKernelGGL(k_sweep_gen<1>, grid, blk, 0, h->stream, a, g);
-  else if (g.K <= 128) hipLaunchKernelGGL(k_sweep_gen<2>, grid, blk, 0, h->stream, a, g);
-  else hipLaunchKernelGGL(k_sweep_gen<4>, grid, blk, 0, h->stream, a, g);
+  const size_t tab = (size_t)3 * g.Mp * 8;
+  a.lds_tab = tab <= 48 * 1024 ? 1 : 0;   // (M <= 2048; wider reporter dimensions read the tables through L2)
+  const size_t sm = a.lds_tab ? tab : 0;
+  if (g.K <= 64) hipLaunchKernelGGL(k_sweep_gen<1>, grid, blk, sm, h->stream, a, g);
+  else if (g.K <= 128) hipLaunchKernelGGL(k_sweep_gen<2>, grid, blk, sm, h->stream, a, g);
+  else hipLaunchKernelGGL(k_sweep_gen<4>, grid, blk, sm, h->stream, a, g);
   HIPCHK(h, hipGetLastError());
   return VMR_OK;
 }
