@@ -234,3 +234,27 @@ def test_lockstep_batch_runs_general_handles_on_their_own():
             e.close()
     for a, b in zip(*outs):
         assert a[1:] == b[1:] and abs(a[0] - b[0]) <= 1e-9 * abs(a[0])
+
+
+def test_layer_sharded_sweeps_of_a_general_handle():
+    """vmr_sweep_local / vmr_commit_nu (the layer-sharded exchange) on a handle of the general kernels: with one owner the exchange is
+    the identity, so it must leave what vmr_step leaves; and the raw pieces must assemble to the oracle's ELBO."""
+    import scipy.special as sp
+    K = 12
+    X, R = _network(2, 20, 9, K, 6, seed=3, mask="ones")
+    a, c = _pair(X, R, K, True, seed=4)
+    b, _ = _pair(X, R, K, True, seed=4)
+    for it in range(3):
+        a.step(1)
+        c.cavi_step()
+        nu_part, e_main, e_q = b.sweep_local(want_elbo=(it == 2))
+        b.commit_nu(nu_part)
+    sa, sb = a.get_state(), b.get_state()
+    for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "rho"):
+        np.testing.assert_allclose(sb[k], sa[k], rtol=1e-10, atol=1e-13, err_msg=k)
+    nu_shp, nu_rte = sb["nu_shp"], sb["nu_rte"]
+    elbo = e_main - (nu_shp / nu_rte) * e_q + float(sp.gammaln(nu_shp) - PRI[4] * np.log(nu_rte) + (PRI[4] - nu_shp) * sp.psi(nu_shp)
+                                                   + nu_shp * (1.0 - PRI[5] / nu_rte))
+    ec = c.elbo()
+    assert abs(elbo - ec) <= 1e-9 * max(1.0, abs(ec)), (elbo, ec)
+    a.close(); b.close()

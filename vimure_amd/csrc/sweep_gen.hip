@@ -81,11 +81,6 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
   const double* lpl = a.logpr + (size_t)l * T * K;
   double* Hl = a.Hg + (size_t)l * g.Y * Mp * K;
   double* Al = a.slotA + ((size_t)l * NSLOT + (gb % NSLOT)) * (size_t)g.W * 64 * K;
-  auto entry = [&](size_t slot, unsigned& ym, unsigned& x, unsigned& inr) {
-    const unsigned e = El[slot];
-    if (EXl) { const unsigned e2 = EXl[slot]; ym = e; x = e2 >> 1; inr = e2 & 1u; }
-    else { ym = SL_YM(e); x = SL_X(e); inr = SL_INR(e); }
-  };
   // the reporters of a partial mask row: f(m) for every m with R[l, tie, m] = 1
   auto for_reporters = [&](unsigned tie, auto&& f) {
     if (rql) {
@@ -104,35 +99,76 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) accF[c] = 0.0;
 
+  constexpr int RB = 8;   // rounds of a step held in registers, one tie's per lane (coalesced loads), handed to the tie's lanes by shuffles
   for (long long s = (long long)gb * nw + wv; s < NS; s += (long long)a.Gl * nw) {
     const unsigned ea = rsl[s];
     const int R = (int)((rsl[s + 1] - ea) >> 6);
+    // what the step's 64 ties need, requested at once, lane <-> position: the class of the mask row, the tie (partial rows), the
+    // ELBO's mirror sum, the first RB rounds of entries -- one memory round trip per step instead of one per tie and round
+    const size_t posl = (size_t)s * 64 + (unsigned)lane;
+    const bool actl = posl < T;
+    const unsigned cls_v = actl ? (cl ? (unsigned)cl[posl] : 1u) : 0u;
+    const unsigned tie_v = (actl && cls_v == 2u) ? pl[posl] : 0u;
+    const unsigned qt_v = (a.elbo && Ql && actl) ? Ql[posl] : 0u;
+    unsigned ent[RB], enx[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const bool on = j < R;
+      ent[j] = on ? El[(size_t)ea + (unsigned)j * 64 + (unsigned)lane] : 0u;
+      enx[j] = (on && EXl) ? EXl[(size_t)ea + (unsigned)j * 64 + (unsigned)lane] : 0u;
+    }
+    // round rr of the tie at position pi: from the registers of lane pi (rr < RB) or from memory (longer steps)
+    auto entry_of = [&](int rr, int pi, unsigned& ym, unsigned& x, unsigned& inr) {
+      unsigned e, e2 = 0u;
+      if (rr < RB) {
+        unsigned ej = ent[0], xj = enx[0];
+#pragma unroll
+        for (int j = 1; j < RB; ++j) { if (rr == j) { ej = ent[j]; xj = enx[j]; } }   // (rr is wave-uniform: a select, no dynamic indexing)
+        e = (unsigned)__shfl((int)ej, pi, 64);
+        if (EXl) e2 = (unsigned)__shfl((int)xj, pi, 64);
+      } else {
+        const size_t slot = (size_t)ea + (unsigned)rr * 64 + (unsigned)pi;
+        e = El[slot];
+        if (EXl) e2 = EXl[slot];
+      }
+      if (EXl) { ym = e; x = e2 >> 1; inr = e2 & 1u; }
+      else { ym = SL_YM(e); x = SL_X(e); inr = SL_INR(e); }
+    };
+    // the log prior / current rho of the first TPW ties; the next ones are requested while these are worked on
+    double lpn[NCH], rn[NCH];
+    auto fetch_sub = [&](int sub_) {
+      const size_t pos_ = (size_t)s * 64 + (unsigned)(sub_ * TPW + grp);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bool on = sub_ < G && pos_ < T && kv[c];
+        lpn[c] = (on && (a.update || a.elbo)) ? lpl[pos_ * K + (c * G + kk)] : 0.0;
+        rn[c] = (on && !a.update) ? rl[pos_ * K + (c * G + kk)] : 0.0;
+      }
+    };
+    fetch_sub(0);
     for (int sub = 0; sub < G; ++sub) {   // the step's 64 ties, TPW at a time
       const int pi = sub * TPW + grp;
       const size_t pos = (size_t)s * 64 + pi;
       const bool act = pos < T;
-      const unsigned cls = act ? (cl ? (unsigned)cl[pos] : 1u) : 0u;
-      const unsigned tie = (act && cls == 2u) ? pl[pos] : 0u;
+      const unsigned cls = (unsigned)__shfl((int)cls_v, pi, 64);
+      const unsigned tie = (unsigned)__shfl((int)tie_v, pi, 64);
+      const unsigned qt = (unsigned)__shfl((int)qt_v, pi, 64);   // (shuffles only where the whole wave passes)
       double lp[NCH], r[NCH];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const bool on = act && kv[c];
-        lp[c] = (on && (a.update || a.elbo)) ? lpl[pos * K + (c * G + kk)] : 0.0;
-        r[c] = (on && !a.update) ? rl[pos * K + (c * G + kk)] : 0.0;
-      }
+      for (int c = 0; c < NCH; ++c) { lp[c] = lpn[c]; r[c] = rn[c]; }
+      fetch_sub(sub + 1);
       double Tt = 0.0;   // sum_m R[tie, m] E[theta_m]
       if (a.update || a.elbo) {
         if (cls == 1u) Tt = Tfull;
         else if (cls == 2u) for_reporters(tie, [&](int m) { Tt += Eth[m]; });
       }
-      const size_t e0 = (size_t)ea + (unsigned)pi;
       if (a.update) {
         double U[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) U[c] = 0.0;
         for (int rr = 0; rr < R; ++rr) {
           unsigned ym, x, inr;
-          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          entry_of(rr, pi, ym, x, inr);
           if (x != 0u) {
             const unsigned y = ym / (unsigned)Mp, m = ym - y * (unsigned)Mp;
             const double lt = Lth[m], gt = Gth[m], dx = (double)x;
@@ -172,7 +208,7 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
       if (a.hist) {
         for (int rr = 0; rr < R; ++rr) {
           unsigned ym, x, inr;
-          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          entry_of(rr, pi, ym, x, inr);
           if (x != 0u && act) {
             double* hrow = Hl + (size_t)ym * K;
             const double dx = (double)x;
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
         for (int c = 0; c < NCH; ++c) er[c] = kv[c] ? exp(r[c]) : 0.0;   // exp(rho), model.py:971
         for (int rr = 0; rr < R; ++rr) {   // (every lane walks every round: the group sums are shuffles)
           unsigned ym, x, inr;
-          entry(e0 + (size_t)rr * 64, ym, x, inr);
+          entry_of(rr, pi, ym, x, inr);
           const unsigned y = ym / (unsigned)Mp, m = ym - y * (unsigned)Mp;
           const double z2 = gnu_e * (double)y, gt = Gth[m];
           double il = 0.0;
@@ -203,7 +239,7 @@ __global__ __launch_bounds__(256) void k_sweep_gen(GenArgs a, Geo g) {
           for (int c = 0; c < NCH; ++c) {
             if (kv[c]) {
               e_lin += r[c] * lp[c] - r[c] * log(r[c] + eps) - r[c] * Ela[c] * Tt;   // model.py:1306-1313, 975-985
-              if (Ql) e_q += r[c] * (double)Ql[pos];
+              if (Ql) e_q += r[c] * (double)qt;
             }
           }
         }

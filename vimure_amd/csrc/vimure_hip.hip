@@ -1968,7 +1968,7 @@ static int launch_gamma(vmr_ctx* h, bool with_phi) {
     const int nh = h->h_reduced ? 1 : NH;
     const size_t fsm = (size_t)2 * ((g.M + FG_G - 1) / FG_G) * 8;
     hipLaunchKernelGGL(g.det ? k_fin_gamma_det : k_fin_gamma, dim3(g.L * FG_G), dim3(FIN_TPB), fsm, h->stream, h->par, h->Hg, h->sparse ? h->Cg : nullptr,
-                       (h->all_full && h->n_partial == 0) ? nullptr : h->slotA,
+                       (h->sparse && skip_full && h->n_partial == 0) ? nullptr : h->slotA,   // (lists, every mask row all ones: the pass summed them into slotF)
                        h->slotF, h->lutg, nullptr, h->fin_g, h->sparse ? h->nu_acc : nullptr, nh,
                        with_phi ? 1 : 0, consume, g);
     h->a_valid = false; h->a_zero = true;   // (k_fin_gamma zeroes the slots of A as it reads them)
@@ -3691,7 +3691,7 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
   if (h->sparse) {   // report lists: 4 B per non-zero count + 4 B per tie; mask words only for partial rows
     const double ties = (double)g.L * g.N * g.N;
     // entries (without the rounds' padding); step pointers: two per 64 ties in the step layout, one in the sorted lists
-    const double E = 4.0 * (double)h->nnz, RP = 4.0 * (ties / 64.0 + g.L);
+    const double E = (g.wide ? 8.0 : 4.0) * (double)h->nnz, RP = 4.0 * (ties / 64.0 + g.L);   // (two-word entries: 8 B per report)
     const double mask = h->all_full ? 0.0 : ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0);
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {
