@@ -111,6 +111,32 @@ def test_categories_beyond_one_wave(K):
     eng.close()
 
 
+@pytest.mark.parametrize("K,mut", [(9, True), (21, True), (70, True), (16, False)])
+def test_sums_over_the_statistics_by_several_workgroups(K, mut, monkeypatch):
+    """Large statistics tables are summed by several workgroups per layer (k_gen_hsum) before / after the finalize kernel: forced
+    here on small ones (VMR_GEN_HSUM), sub-steps and fused sweeps against the oracle as above."""
+    from vimure_amd import _lib
+    monkeypatch.setenv("VMR_GEN_HSUM", "3")
+    X, R = _network(2, 19, 70, K, 5, seed=K + 1, mask="words", dens=0.05)
+    eng, c = _pair(X, R, K, mut, seed=4)
+    eng.sub_step(_lib.STEP_GAMMA); c.update_gamma()
+    g = eng.get_state(rho=False)
+    np.testing.assert_allclose(g["gamma_shp"], c.gamma_shp, rtol=1e-9)
+    np.testing.assert_allclose(g["gamma_rte"], c.gamma_rte, rtol=1e-9)
+    eng.sub_step(_lib.STEP_PHI); c.update_phi()
+    g = eng.get_state(rho=False)
+    np.testing.assert_allclose(g["phi_shp"], c.phi_shp, rtol=1e-9)
+    np.testing.assert_allclose(g["phi_rte"], c.phi_rte, rtol=1e-9)
+    for _ in range(3):
+        c.cavi_step()
+        eng.step(1)
+    st = eng.get_state()
+    for n in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte"):
+        np.testing.assert_allclose(st[n], getattr(c, n), rtol=1e-9, err_msg=n)
+    np.testing.assert_allclose(st["rho"], c.rho, rtol=1e-8, atol=1e-13)
+    eng.close()
+
+
 def test_mutuality_off_sixteen_categories():
     X, R = _network(2, 20, 72, 16, 5, seed=8, mask="words", dens=0.03)
     eng, c = _pair(X, R, 16, False, seed=2)

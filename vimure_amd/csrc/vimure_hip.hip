@@ -2319,7 +2319,8 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     }
     CK(hipMalloc(&h->Hg, (size_t)hb));
     CK(hipMemsetAsync(h->Hg, 0, (size_t)hb, h->stream));
-    CK(hipMalloc(&h->gen_s1, (size_t)L * g.Mp * 8));
+    CK(hipMalloc(&h->gen_s1, (size_t)L * (g.Mp + K + 1) * 8));   // (zero between uses: the readers zero what they read)
+    CK(hipMemsetAsync(h->gen_s1, 0, (size_t)L * (g.Mp + K + 1) * 8, h->stream));
     CK(hipMalloc(&h->elbo_dev, 8 * 8));
     CK(hipMemsetAsync(h->elbo_dev, 0, 8 * 8, h->stream));
     CK(hipMalloc(&h->nu_acc, (size_t)(3 + L) * 8));
@@ -3013,6 +3014,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   h->f_valid = false;
   h->a_valid = false;
   h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
+  if (h->gen_s1) HIPCHK(h, hipMemsetAsync(h->gen_s1, 0, (size_t)h->g.L * (h->g.Mp + h->g.K) * 8, h->stream));
   return VMR_OK;
 }
 

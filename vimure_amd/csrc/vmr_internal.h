@@ -90,7 +90,7 @@ struct vmr_ctx {
   int sparse = 0;
   unsigned* E = nullptr;       // one entry per non-zero count, layer after layer
   unsigned* EX = nullptr;      // wide entries (Geo::wide): E holds the table row y * Mp + m in 32 bits, EX the count << 1 | R[l,i,j,m], same slots
-  double* gen_s1 = nullptr;    // [L][Mp] scratch of k_fin_gamma_gen
+  double* gen_s1 = nullptr;    // [L][Mp] + [L][K] scratch of the general finalize (sums over H by reporter, by category) + [L] step counters of the pass
   unsigned* rs = nullptr;      // [L][N*N/64+1] first entry of every 64-tie step, relative to ebase[l]
   double* Cg = nullptr;        // [L][Y][Mp] sum of the counts x per (mirror count, reporter): what H_0 is rebuilt from
   int sp_tpb = 256;            // threads per workgroup of the report-list passes that update rho or reduce the ELBO
