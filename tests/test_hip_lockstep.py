@@ -161,3 +161,19 @@ def test_lockstep_at_the_largest_village_against_the_oracle():
 def test_lockstep_three_categories_two_layers_against_the_oracle():
     """K = 3, L = 2 units in one lockstep launch, each against the oracle (not only against its own single loop)."""
     _against_oracle([_village(N, 60 + s, K=3, L=2) for s, N in enumerate([44, 57, 70])], 3, 31)
+
+
+def test_groups_on_several_lanes_give_the_same_fits():
+    """Groups of `width` units worked on by several host threads at once (fit_units_lockstep(lanes=...): one group's host share
+    beside another's lockstep loop) give, fit by fit, what one lane gives."""
+    from vimure_amd.batch import fit_units_lockstep
+    units = [(i,) + _village(N, 70 + i) for i, N in enumerate([40, 52, 64, 45, 58])]
+    kw = dict(num_realisations=2, max_iter=21)
+    one = fit_units_lockstep(units, 2, [1, 2], True, None, kw, width=2, lanes=1)
+    three = fit_units_lockstep(units, 2, [1, 2], True, None, kw, width=2, lanes=3)
+    assert sorted(one) == sorted(three) == list(range(5))
+    for tag in one:
+        a, b = one[tag][0], three[tag][0]
+        assert [(r["seed"], r["iters"], r["converged"]) for r in a] == [(r["seed"], r["iters"], r["converged"]) for r in b]
+        np.testing.assert_allclose([r["elbo"] for r in b], [r["elbo"] for r in a], rtol=1e-10)
+        np.testing.assert_allclose([r["nu"] for r in b], [r["nu"] for r in a], rtol=1e-9)
