@@ -234,6 +234,13 @@ int vmr_data_format(vmr_handle h, int* sparse, uint64_t* nnz);
  * those lists.  The bit-packed mask is kept either way.  Either pointer may be NULL. */
 int vmr_mask_format(vmr_handle h, int* lists, uint64_t* listed);
 
+/* Shape of a sweep over the report lists (no reference equivalent; what `_update_CAVI`, model.py:623-660, costs here):
+ * *passes = passes over the entries per sweep (1, or 2 where the tables of a wide reporter dimension do not fit in LDS side
+ * by side), *lds_levels = mirror-count levels of the statistics H the pass keeps in LDS, *far_reports = reports of the
+ * levels beyond that a one-pass handle built with env VMR_FARL=1 also keeps as a compact list (k_far_hist adds their
+ * statistics after the pass; default: two passes instead).  Dense tiles: 1 (2), the LDS levels, 0.  Any pointer may be NULL. */
+int vmr_sweep_shape(vmr_handle h, int* passes, int* lds_levels, uint64_t* far_reports);
+
 /* Synthetic generators on the device (no handle: they produce the inputs of vmr_create).
  * vmr_generate_y replaces the ground-truth draw of the reference's StandardSBM (synthetic.py:548-571, 639-667):
  * Y[l,i,j] ~ Poisson(w[grp[i]][grp[j]]) clipped to K - 1, zero diagonal.  w [C][C] and grp [N] are host arrays, Y_dev a

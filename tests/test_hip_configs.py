@@ -137,12 +137,14 @@ def test_config3_full_size_fit_stops_where_the_oracle_stops():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mode", ["default", "small_workgroups", "one_pass_two_levels", "two_passes", "no_lds_levels"])
+@pytest.mark.parametrize("mode", ["default", "small_workgroups", "one_pass_two_levels", "two_passes", "no_lds_levels", "far_lists",
+                                  "far_lists_two_levels", "far_lists_small_workgroups"])
 def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     """One layer in the regime of BASELINE configs[4] (M = 1000 reporters, K = 3, mutuality on): a level of the factor
     table F or of the statistics H is 24 KB here, so only a few levels of each fit in LDS beside each other.  The engine
-    then either keeps what fits in one pass (the rest is read from / added to global memory) or rebuilds H in a second
-    pass; every shape is held to the oracle, including no LDS level at all."""
+    then either rebuilds H in a second pass (the default here and at configs[4]'s size), or keeps what fits in one pass -- the
+    reports of the levels beyond added to global memory by the pass itself, or (VMR_FARL=1) kept as a compact list as well, whose
+    statistics a small kernel adds after the pass; every shape is held to the oracle, including no LDS level at all."""
     import torch
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
@@ -150,13 +152,21 @@ def test_config5_regime_wide_reporter_dimension(mode, monkeypatch):
     env = {"small_workgroups": {"VMR_TPB": "128", "VMR_ST_TPB": "256"},   # (more workgroups, fewer waves behind each ticket counter)
            "one_pass_two_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "2", "VMR_HC": "2"},
            "two_passes": {"VMR_TWO_PASS": "1", "VMR_YT": "5", "VMR_HC": "5"},
-           "no_lds_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "0", "VMR_HC": "0", "VMR_TPB": "256"}}.get(mode, {})
+           "no_lds_levels": {"VMR_TWO_PASS": "0", "VMR_YT": "0", "VMR_HC": "0", "VMR_TPB": "256"},
+           "far_lists": {"VMR_FARL": "1"},
+           "far_lists_two_levels": {"VMR_FARL": "1", "VMR_YT": "2", "VMR_HC": "2"},
+           "far_lists_small_workgroups": {"VMR_FARL": "1", "VMR_TPB": "128", "VMR_ST_TPB": "256"}}.get(mode, {})
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     L, N, M, K = 1, 1500, 1000, 3
     net = standard_sbm(N=N, M=M, L=L, K=K, C=2, avg_degree=5.0, sparsify=True, eta=0.5, seed=2, device="cuda:0")
     eng = CaviEngine(net.X, None, K=K, mutuality=True, device=0)
     assert eng.data_format()[0] == "sparse"
+    passes, levels, far = eng.sweep_shape()
+    if mode.startswith("far_lists"):
+        assert passes == 1 and far > 0 and (mode != "far_lists_two_levels" or levels == 2), (passes, levels, far)
+    elif mode in ("default", "two_passes", "small_workgroups"):
+        assert passes == 2 and far == 0, (passes, levels, far)
     sum_x, cov = eng.data_stats()
     init = _host_state(L, N, M, K, True, 3, sum_x, cov)
     subs, vals = _coo_from_device(net.X)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vmr_kernel_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "vmr_data_format": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "vmr_mask_format": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "vmr_sweep_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "vmr_generate_y": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vmr_generate_x": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                  C.c_uint64, C.c_int, C.c_void_p]),

@@ -10,7 +10,9 @@
 //                         per-(y, m) tables F and H        bit 20  R[l,i,j,m]        bits 21..31  the count x (<= 2047)
 //     rs[l][s] (u32, NS + 1 per layer)   first slot of step s;  R_s = (rs[s+1] - rs[s]) / 64, non-increasing in s
 //     perm[l][pos] (u32)                 the tie (i * N + j) at sorted position pos (0xffffffff beyond the last tie)
-//     sy[l][s] (u32)                     the highest mirror count y among the step's reports (which table levels it needs)
+//     sy[l][s] (u32)                     bits 0..15: the highest mirror count y among the step's reports (which table levels it needs);
+//                                        bits 16..31 (Geo::farl): the step's reports of the levels beyond the LDS ones are its ties' FIRST
+//                                        ones -- rounds 0 .. nf - 1 -- and this is nf (k_far_first)
 // Padding only appears in the ~max-count steps per layer where the count changes.  Every per-tie array the sweeps touch is
 // stored BY POSITION (rho, log prior, mask-row class, the ELBO's mirror sums Qt), so all of a wave's accesses are contiguous;
 // the boundary functions (vmr_set_state, vmr_get_state, vmr_readout, vmr_sample) translate through perm.
@@ -67,6 +69,11 @@ struct SlArgs {
   // Every tie of a step WITHOUT reports carries the reference's one-hot prior (1, 0, .., 0) (model.py:536-556; found at vmr_set_state):
   // such steps -- 99.99 % of a survey layer's -- take log(1 + eps), log(eps) from registers instead of 8 K bytes per tie from memory.
   int lp0;
+  // Geo::farl: reports of levels beyond the LDS ones add nothing to H here (k_far_hist does, from the compact far lists, and
+  // finishes nu): no global adds in the pass, and the grid's last workgroup leaves the nu sum standing.
+  int farl;
+  const unsigned* Ez;   // 64 empty entries (the zeroed slack behind E): what the ring of a long step loads past the step's last round
+  int elbo_cur;   // ELBO-only pass: the CURRENT G_nu, not the stale one -- nu was not committed since the rho it evaluates (split ELBO sweep of vmr_sweep_local)
 #ifdef SL_DEBUG
   unsigned long long* dbg_t;   // [waves][8]: a wave's start, end of prologue, end of step loop, end; first loads issued, tables' barrier, nu share done, flush done (100 MHz clock)
 #endif
@@ -98,7 +105,7 @@ constexpr int sl_wpe(int K, bool elbo, bool allfull, bool update = true) {
 static inline size_t sl_smem(const Geo& g, int yt, int hc, bool update, bool elbo, bool hist) {
   const size_t lb = (size_t)g.Mp * g.K * 8;
   return (update ? (size_t)yt * lb : 0) + (hist ? (size_t)hc * lb : 0) + (size_t)g.Mp * 8 * (update ? 2 : 1) +
-         (size_t)g.W * 8 + 128 + (g.ml ? lb + (size_t)g.Mp * 8 : 0) + (size_t)SP_MATH_DOUBLES * 8 + 16;
+         (size_t)g.W * 8 + 128 + (g.ml ? lb + (size_t)g.Mp * 8 : 0) + (size_t)(64 + (elbo ? 256 : 0)) * 8 + 16;   // (the logarithm table: ELBO variants only)
 }
 
 // mode: 0 = rho update (+ H), 1 = rho update + ELBO data terms, 2 = ELBO only, 3 = statistics only (do_hist 1 or 2),

@@ -87,7 +87,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   double* wsum = reinterpret_cast<double*>(smem + off); off += (size_t)g.W * 8;
   double* red = reinterpret_cast<double*>(smem + off); off += 16 * 8;
   double* xt = reinterpret_cast<double*>(smem + off); off += 64 * 8;
-  double* lt = reinterpret_cast<double*>(smem + off); off += 256 * 8;
+  double* lt = reinterpret_cast<double*>(smem + off); off += ELBO ? 256 * 8 : 0;
   double* EthL = reinterpret_cast<double*>(smem + off); off += a.rq ? (size_t)Mp * 8 : 0;   // E[theta] for the mask lists
   const ParOff o = par_off(g.L, g.Mp, g.K);
   const int l = (int)bx / a.Gl, gb = (int)bx - l * a.Gl;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
 #endif
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);
-  const double gnu = a.par[o.sc + (UPDATE ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  const double gnu = a.par[o.sc + ((UPDATE || a.elbo_cur) ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
   for (int m = tid; m < Mp; m += nthr) {
     Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
     if (UPDATE) Lth[m] = a.par[o.l_th + (size_t)l * Mp + m];
@@ -105,7 +105,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
   if (a.sum_a) for (int q = tid; q < Mp * K; q += nthr) As[q] = 0.0;
   if (a.rq) for (int m = tid; m < Mp; m += nthr) EthL[m] = m < g.M ? a.par[o.E_th + (size_t)l * Mp + m] : 0.0;
-  if (UPDATE || ELBO) sp_math_tables(xt, lt, tid, nthr);
+  if (UPDATE || ELBO) sp_math_tables(xt, lt, tid, nthr, ELBO);
   const double* lut = a.lutg + (size_t)l * g.W * 256;
   for (int w = tid; w < g.W; w += nthr) {
     double v = 0.0;
@@ -179,6 +179,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   unsigned ea = 0;    // first slot of the current step
   int R = 0;          // its rounds
   unsigned ymax = 0;  // its highest mirror-count level
+  unsigned nfar = 0;  // Geo::farl: its leading rounds that may hold reports of the levels beyond the LDS ones (sy, high half)
   unsigned rgv = 0;   // lanes 0..2: rs[s2], rs[s2 + 1], sy[s2] of the NEXT step (loaded one step earlier)
   StepIn<K> P;        // the prefetched step
 
@@ -223,7 +224,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   if (s < NS) {   // prologue: this wave's first step
     ea = rsl[s];
     R = (int)((rsl[s + 1] - ea) >> 6);
-    ymax = syl[s];
+    { const unsigned syv = syl[s]; ymax = syv & 0xffffu; nfar = syv >> 16; }
     fetch_range(sn < NS ? sn : s);
     fetch_tie(P, s);
     fetch_ent(P, ea, RC<PFK>{});
@@ -411,32 +412,38 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // ---- one step: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general (far levels, or more rounds) --
   // ---- the work of one step on its loaded values: RCT = its rounds (0..SL_PF, compile time: straight-line walks), -1 = general
   // (far levels, or more rounds).  row0 / act: the step's first position, this lane's tie exists; ea_c, Rr: its slots and rounds.
-  auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned ymax) SL_INL {
+  // nf: only the step's rounds 0 .. nf - 1 can hold reports of the levels beyond the LDS ones (Geo::farl: the lists are ordered that way;
+  // otherwise every round can)
+  auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned ymax,
+                     const unsigned nf) SL_INL {
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
     // The rounds of a general step, ONE loop for all of them so that the per-round code exists PFK times and no more (a
     // body of tens of kilobytes does not stay in the instruction cache: a cut with the prefetched rounds and the ring walked
     // by separate code, far levels handled in line, was 68-183 KB per kernel and spent a third of its wave time waiting to
-    // issue).  The ring starts from the prefetched rounds and keeps PFK loads in flight over the further ones, clamped
-    // to the step's last round: no branch around a load.  use(c, GB entries) for groups of GB rounds, in order; rounds past
-    // the last are empty entries (x = 0, row 0).
-    auto ring_addr = [&](int j) SL_INL { const int jj = j < Rr ? j : (Rr > 0 ? Rr - 1 : 0); return (size_t)ea_c + (unsigned)lane + (unsigned)jj * 64; };
+    // issue).  The ring starts from the prefetched rounds and keeps PFK loads in flight over the further ones: no branch around
+    // a load -- past the step's last round it loads empty entries (x = 0, row 0) from the zeroed slack behind the lists, through
+    // a wave-uniform pointer (scalar base + one per-lane offset register: no vector instruction per load but the load, no select
+    // per entry; round 4 -- the general body issued 57 vector instructions per round of a config-5 layer).
+    // use(c, j): GB entries of rounds j .. j + GB - 1, in order.
+    const unsigned* pe = El + ea_c;
     auto rounds = [&](auto gbc, auto&& use) SL_INL {
       constexpr int GB = decltype(gbc)::value;
       unsigned rg[PFK];   // the ring: PFK loads in flight, starting from the prefetched rounds
 #pragma unroll
-      for (int i = 0; i < PFK; ++i) rg[i] = cur.e[i];
+      for (int i = 0; i < PFK; ++i) rg[i] = i < Rr ? cur.e[i] : 0u;   // (a general step may be a short one: its prefetch then read later steps' slots)
       for (int j0 = 0; j0 < Rr; j0 += PFK) {
 #pragma unroll
         for (int gi = 0; gi < PFK; gi += GB) {
           unsigned c[GB];
 #pragma unroll
           for (int u = 0; u < GB; ++u) {
-            c[u] = (j0 + gi + u < Rr) ? rg[gi + u] : 0u;   // (wave-uniform select)
-            rg[gi + u] = El[ring_addr(j0 + gi + u + PFK)];
+            c[u] = rg[gi + u];
+            const int jn = j0 + gi + u + PFK;
+            rg[gi + u] = *at_bytes(jn < Rr ? pe + (size_t)jn * 64 : a.Ez, lane4);
           }
-          if (j0 + gi < Rr) use(c);   // (wave-uniform)
+          if (j0 + gi < Rr) use(c, (unsigned)(j0 + gi));   // (wave-uniform)
         }
       }
     };
@@ -468,8 +475,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // others read row 0 with x = 0); lanes whose row lies beyond take the table's formula, per entry and only where some
         // lane needs it.  Rounds past the step's last are empty entries.
         constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
-        rounds(RC<GB>{}, [&](const unsigned (&c)[GB]) SL_INL {
-          if (ymax < lim1) { walk1_near(c, RC<GB>{}, U); return; }   // (this step's reports all lie in the LDS levels of F: known per step)
+        rounds(RC<GB>{}, [&](const unsigned (&c)[GB], const unsigned j) SL_INL {
+          if (ymax < lim1 || j >= nf) { walk1_near(c, RC<GB>{}, U); return; }   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)
           double f[GB][K];
           bool fr[GB];
 #pragma unroll
@@ -586,17 +593,29 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       } else {
         // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
         // beyond the levels go to global memory, per entry and only where some lane needs it
-        rounds(RC<1>{}, [&](const unsigned (&c1)[1]) SL_INL {
-          const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
-          const bool fr = lim2 != 0xffffffffu && ym >= hcm;
-          const double dx = fr ? 0.0 : (double)x;
-          if (a.do_hist) {
-            const unsigned row = fr ? 0u : ym;
+        rounds(RC<1>{}, [&](const unsigned (&c1)[1], const unsigned j) SL_INL {
+          if (j >= nf || lim2 == 0xffffffffu) {   // no report of this round lies beyond the LDS levels: what the straight-line walk does per report
+            const unsigned cn = c1[0], ymn = SL_YM(cn);
+            const double dxn = (double)SL_X(cn);
+            if (a.do_hist) {
 #pragma unroll
-            for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + row], dx * r[k], sc_h);
-            if (irr) lds_add(&Hc[row], dx * dfc, sc_h);   // (wave-uniform: some tie of the step does not sum to 1)
-            if (__any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
-              if (fr && x != 0u) {   // table by the grid's last workgroup (nu_far).
+              for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ymn], dxn * r[k], sc_h);
+              if (irr) lds_add(&Hc[ymn], dxn * dfc, sc_h);
+            }
+            if (ELBO) { const double term = dxn * log_tab(elbo_inner(cn, er), lt); if (DET) ie_log += fxm(term, sc_r); else e_log += term; }
+            return;
+          }
+          const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
+          const bool fr = ym >= hcm;
+          const double dx = (double)x;
+          if (a.do_hist) {
+            if (!fr && x != 0u) {   // (far lanes and empty slots add nothing: zeros added to one common row would serialise them)
+#pragma unroll
+              for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
+              if (irr) lds_add(&Hc[ym], dx * dfc, sc_h);   // (wave-uniform: some tie of the step does not sum to 1)
+            }
+            if (!a.farl && __any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
+              if (fr && x != 0u) {       // table by the grid's last workgroup (nu_far).  (farl: k_far_hist adds them.)
                 if (DET) {
                   unsigned long long* d0 = a.det;
                   asm volatile("" : "+s"(d0));   // (keeps this address arithmetic inside the rare branch: hoisted, it cost every variant ten registers)
@@ -645,7 +664,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     const bool more = s2 < NS;
     const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
     const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
-    const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
+    const unsigned sy2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u, ym2 = sy2 & 0xffffu, nf2 = sy2 >> 16;
     fetch_range(s3 < NS ? s3 : s);
     fetch_tie(P, more ? s2 : s, RCT == 0 && a.lp0 != 0);   // (sorted order: after a step without reports come only such steps)
     if (RCT >= 0 || PFK <= 8) fetch_ent(P, ea2, RC<NP>{});
@@ -659,7 +678,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         }
       }
     }
-    compute(rct, cur, row0, act, ea_c, Rr, ymax);
+    compute(rct, cur, row0, act, ea_c, Rr, ymax, a.farl ? nfar : 0x7fffffffu);
     // Everything the NEXT step needs was requested at the top of this one: wait for it HERE, before the next step's own
     // requests go out.  (Left to itself the compiler waits at the first use, after those requests -- and where it cannot tell
     // how many requests are younger than the ones it needs it drains them all: memory latency in every step.)  This step's rho
@@ -670,7 +689,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     if (RCT >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);   // vmcnt(NST)
     else __builtin_amdgcn_s_waitcnt(0x0F70);                  // (general steps may add global atomics: vmcnt(0))
     // advance
-    s = s2; sn = s3; ea = ea2; R = R2; ymax = ym2;
+    s = s2; sn = s3; ea = ea2; R = R2; ymax = ym2; nfar = nf2;
   };
   // consecutive steps of this wave with the same number of rounds run in one straight-line loop
   auto run = [&](auto rct) SL_INL {
@@ -759,7 +778,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (nu_last) {
+    if (nu_last && a.farl) {   // k_far_hist adds the far levels' share and finishes nu: the sum stays, the ticket is reset
+      if (tid == 0) a.nu_acc[1] = 0.0;
+    } else if (nu_last) {
       // nu_far: what went to the global table directly -- reports of levels beyond the LDS copies (rows y >= hc: categories
       // k > 0 and, in slot 0, the deficits of irregular ties) -- weighted like the rest; every workgroup's adds were performed
       // before its ticket.  Usually all zero: the loads are the cost ((Y - hc) Mp K NH values over the workgroup).

@@ -1760,7 +1760,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0};
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, h->E + h->n_slots, 0};
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -1795,6 +1795,185 @@ static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
     default: { constexpr int PP = 12; DISPATCH_K(K_, __VA_ARGS__); } break; \
   }
 
+
+
+// ------------------------------------------------------------------------------------------
+// Geo::farl -- the reports of the levels beyond the LDS ones
+// ------------------------------------------------------------------------------------------
+// Geo::farl: every tie's reports of the levels beyond the LDS ones (row >= rows_near) are moved to the FRONT of its list -- one wave
+// per step, a lane walks its tie's column and swaps a far report with the first near one -- so that only the first nf rounds of a
+// step (nf = the most far reports any of its 64 ties has; stored in the high half of sy) ever take the pass' far-level code: left
+// where they fall, 2 % of far reports put one into two rounds of three.
+__global__ __launch_bounds__(256) void k_far_first(unsigned* __restrict__ E, const unsigned* __restrict__ rsl, unsigned* __restrict__ syl, size_t NS, unsigned rows_near) {
+  const int lane = threadIdx.x & 63;
+  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
+    const unsigned ea = rsl[s], R = (rsl[s + 1] - ea) >> 6;
+    unsigned* col = E + (size_t)ea + lane;
+    unsigned f = 0;   // far reports found so far = the slot the next one goes to
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned e = col[(size_t)r * 64];
+      if (e != 0u && SL_YM(e) >= rows_near) {
+        if (f != r) { const unsigned o = col[(size_t)f * 64]; col[(size_t)f * 64] = e; col[(size_t)r * 64] = o; }
+        ++f;
+      }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) f = max(f, (unsigned)__shfl_xor((int)f, o2, 64));
+    if (lane == 0) syl[s] = (syl[s] & 0xffffu) | (min(f, 0xffffu) << 16);
+  }
+}
+
+// One wave per step of the sorted lists: (position, entry) of every report whose mirror count is at least yfar, appended to the
+// layer's far list (order immaterial: their sums are float atomics anyway).
+__global__ __launch_bounds__(256) void k_far_collect(const unsigned* __restrict__ E, const unsigned* __restrict__ rsl, size_t NS, unsigned rows_near,
+                                                     unsigned* __restrict__ far_pos, unsigned* __restrict__ far_ent, unsigned long long* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
+    const unsigned ea = rsl[s], R = (rsl[s + 1] - ea) >> 6;
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned e = E[(size_t)ea + r * 64 + lane];
+      const bool far = e != 0u && SL_X(e) != 0u && SL_YM(e) >= rows_near;
+      const unsigned long long bal = __ballot(far);
+      if (bal == 0ull) continue;
+      unsigned long long base = 0ull;
+      if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
+      base = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(base >> 32), 0, 64) << 32) | (unsigned)__shfl((int)(unsigned)base, 0, 64);
+      if (far) {
+        const unsigned long long at = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+        far_pos[at] = (unsigned)(s * 64 + (unsigned)lane);
+        far_ent[at] = e;
+      }
+    }
+  }
+}
+
+// The statistics of the far reports: H[y][m][k] += x rho_k (k >= 1; the deficits of ties whose rho does not sum to 1 in slot 0)
+// for the reports of levels y >= hc, which the pass left out -- the next LF levels in LDS (float atomics, as the pass' own), any
+// beyond those as global adds -- and their share of nu_shp - alpha = sum x rho_k w2_k (model.py:820-830).  The grid's last
+// workgroup finishes nu exactly as the pass' does where it keeps every level (sweep_sl.hip).  rho is gathered by position: a few
+// per cent of the reports.  count: the constants' pass of vmr_create (every tie "is" category 1).
+template <int K>
+__global__ __launch_bounds__(1024) void k_far_hist(const unsigned* __restrict__ far_pos, const unsigned* __restrict__ far_ent,
+                                                   const unsigned long long* __restrict__ fbase, const double* __restrict__ rho, double* Hg, double* par,
+                                                   double* nu_acc, double* elbo_dev, int count, int commit_nu, int Gl, int LF, Geo g) {
+  extern __shared__ double Hf[];   // [K][LF][Mp], 16 doubles for the block sums
+  const int Mp = g.Mp, tid = threadIdx.x, nthr = (int)blockDim.x;
+  const int l = (int)blockIdx.x / Gl, gb = (int)blockIdx.x - l * Gl;
+  const unsigned lfm = (unsigned)LF * (unsigned)Mp, hcm = (unsigned)g.hc * (unsigned)Mp;
+  double* red = Hf + (size_t)K * lfm;
+  for (unsigned q = tid; q < (unsigned)K * lfm; q += nthr) Hf[q] = 0.0;
+  __syncthreads();
+  const ParOff o = par_off(g.L, Mp, g.K);
+  const size_t T = (size_t)g.N * g.N;
+  double Gla[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) Gla[k] = par[o.G_la + l * K + k];
+  const double gnu = par[o.sc + SC_G_NU];
+  const double* gth = par + o.G_th + (size_t)l * Mp;
+  const double* rl = rho + (size_t)l * T * K;
+  double* Hl = Hg + ((size_t)l * NH + (gb % NH)) * g.Y * Mp * K;
+  double share = 0.0;
+  const unsigned long long i1 = fbase[l + 1];
+  constexpr int FB = 4;   // reports in flight per thread (the gathers of rho are what this kernel waits for)
+  for (unsigned long long i0 = fbase[l] + (unsigned long long)gb * nthr * FB + tid; i0 < i1; i0 += (unsigned long long)Gl * nthr * FB) {
+    unsigned pos[FB], ent[FB];
+    double r[FB][K];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * nthr;
+      const bool on = i < i1;
+      pos[u] = on ? far_pos[i] : 0u;
+      ent[u] = on ? far_ent[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) r[u][k] = count ? (k == 1 ? 1.0 : 0.0) : (ent[u] ? rl[(size_t)pos[u] * K + k] : 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      if (ent[u] == 0u) continue;
+      const unsigned ym = SL_YM(ent[u]), rel = ym - hcm;
+      const double dx = (double)SL_X(ent[u]);
+      double sm = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sm += r[u][k];
+      double dfc = 1.0 - sm;
+      if (fabs(dfc) <= 1e-14) dfc = 0.0;   // (as the pass decides it)
+      if (rel < lfm) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&Hf[(unsigned)k * lfm + rel], dx * r[u][k]);
+        if (dfc != 0.0) atomicAdd(&Hf[rel], dx * dfc);
+      } else {
+        double* d = Hl + (size_t)ym * K;
+#pragma unroll
+        for (int k = 1; k < K; ++k) atomicAdd(&d[k], dx * r[u][k]);
+        if (dfc != 0.0) atomicAdd(&d[0], dx * dfc);
+      }
+      if (nu_acc) {
+        const unsigned y = ym / (unsigned)Mp, m = ym - y * (unsigned)Mp;
+        const double z2 = gnu * (double)y, gt = gth[m];
+        const double d0 = gt * Gla[0] + z2, w0 = d0 == 0.0 ? 0.0 : z2 / d0;
+        share -= w0 * dx * dfc;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          const double dk = gt * Gla[k] + z2;
+          share += ((dk == 0.0 ? 0.0 : z2 / dk) - w0) * dx * r[u][k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned q = tid; q < (unsigned)K * lfm; q += nthr) {
+    const double v = Hf[q];
+    if (v != 0.0) { const unsigned k = q / lfm, rel = q - k * lfm; atomicAdd(&Hl[(size_t)(hcm + rel) * K + k], v); }
+  }
+  if (!nu_acc) return;
+  share = block_sum_n(share, red);
+  __shared__ int last;
+  if (tid == 0) {
+    atomicAdd(&nu_acc[0], share);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's share is performed at the memory side before the ticket is drawn)
+    const double t = atomicAdd(&nu_acc[1], 1.0);
+    last = (t == (double)(gridDim.x - 1u));
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      double tot = atomicAdd(&nu_acc[0], 0.0);   // the pass' workgroups' shares and this kernel's (device-scope read)
+      for (int ll = 0; ll < g.L; ++ll) tot += nu_acc[2 + ll];
+      nu_acc[0] = 0.0; nu_acc[1] = 0.0;
+      elbo_dev[1] = tot;   // the raw piece, for fits whose layers are spread over several handles (vmr_sweep_local)
+      if (commit_nu) {
+        double* sc = par + o.sc;
+        sc[SC_G_NU_STALE] = sc[SC_G_NU];           // what the last cache refresh held (model.py:684)
+        sc[SC_NU_SHP] = sc[SC_A_ETA] + tot;
+        sc[SC_G_NU] = exp(digamma_pos(sc[SC_NU_SHP]) - log(sc[SC_NU_RTE]));
+        sc[SC_E_NU] = sc[SC_NU_SHP] / sc[SC_NU_RTE];
+      }
+    }
+  }
+}
+// nu: -1 = no nu sum in this sweep; 0 = the raw sum to elbo_dev[1]; 1 = nu committed too (as launch_hist's)
+static int launch_far(vmr_ctx* h, int count, int nu) {
+  const Geo& g = h->g;
+  if (!g.farl || h->far_off.empty() || h->far_off.back() == 0ull) {
+    if (nu >= 0 && g.farl) return fail(h, VMR_ESTATE, "far lists missing");   // (cannot happen: farl is only chosen with far reports)
+    return VMR_OK;
+  }
+  const size_t lb = (size_t)g.Mp * g.K * 8;
+  const int LF = (int)std::max<size_t>(1, std::min<size_t>((size_t)(g.Y - g.hc), ((size_t)150 * 1024 - 256) / lb));
+  const size_t sm = (size_t)LF * lb + 16 * 8;
+  unsigned long long most = 0;
+  for (int l = 0; l < g.L; ++l) most = std::max(most, h->far_off[l + 1] - h->far_off[l]);
+  const int Gl = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((most + 4095) / 4096, std::max(1, h->ncu / g.L)));
+  double* nu_acc = (nu >= 0 && g.mut) ? h->nu_acc : nullptr;
+  Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
+  DISPATCH_K(g.K, if (sm > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_far_hist<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+             hipLaunchKernelGGL((k_far_hist<KK>), dim3(g.L * Gl), dim3(1024), sm, h->stream, h->far_pos, h->far_ent, h->far_base, h->rho, h->Hg, h->par,
+                                nu_acc, h->elbo_dev, count, nu > 0 ? 1 : 0, Gl, LF, g));
+  HIPCHK(h, hipGetLastError());
+  return VMR_OK;
+}
 
 // k_fin_rho: nu and/or the ELBO; folds the NH copies of H into copy 0 on its way when they are not folded yet
 static int launch_fin_rho(vmr_ctx* h, int do_nu, int do_elbo, int skip_nu = 0) {
@@ -1889,6 +2068,7 @@ static int launch_hist(vmr_ctx* h, int nu = -1) {
     int rcs = sl_launch(h, 3, shs, as);
     if (rcs) return rcs;
     HIPCHK(h, hipGetLastError());
+    if (g.farl && (rcs = launch_far(h, 0, (nu >= 0 && g.mut) ? nu : -1))) return rcs;
     if ((rcs = det_fold(h))) return rcs;
   } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
@@ -1998,6 +2178,21 @@ static int launch_phi(vmr_ctx* h) {
 static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false, bool store = true) {
   const Geo& g = h->g;
   if (g.gen) return gen_rho(h, mode, commit_nu, raw_nu, [](vmr_ctx* hh, int do_nu, int do_elbo, int skip_nu) { return launch_fin_rho(hh, do_nu, do_elbo, skip_nu); });
+  if (h->sparse && g.farl && h->elbo_split && mode == 1) {
+    // An ELBO sweep of a handle whose fused variant would drop an LDS level: the plain update pass (with the far reports' kernel and
+    // nu), then the ELBO-only pass on the new rho with the G_nu of before the commit -- what the fused pass evaluates (model.py:970).
+    int rc2 = launch_rho(h, 0, commit_nu, raw_nu, true);
+    if (rc2) return rc2;
+    const SlShape she = sl_shape(h, false, true, false);
+    SlArgs ae = sl_args(h, she, 0, 0);
+    ae.elbo_cur = commit_nu ? 0 : 1;
+    {
+      Prof p(h, VMR_KERNEL_ELBO);
+      if ((rc2 = sl_launch(h, 2, she, ae))) return rc2;
+    }
+    HIPCHK(h, hipGetLastError());
+    return launch_fin_rho(h, 0, 1, 1);
+  }
   RhoArgs a{h->X, h->Rb, h->rho, h->logpr, h->par, h->slotR, h->lutg, h->Hg, h->slotF, 1};
   size_t sm = shmem_rho(g, mode != 2, mode != 0);
   dim3 blk(TPB);
@@ -2023,12 +2218,13 @@ static int launch_rho(vmr_ctx* h, int mode, bool commit_nu, bool raw_nu = false,
     // (the re-write of ensure_rho takes the nu before that commit from SC_G_NU_STALE) or without mutuality, in one pass per sweep
     // -- and only where the pass itself sums rho over the mask rows: the mask kernels of launch_gamma read rho from memory
     const bool lazy = !store && mode == 0 && do_hist && (nu_in_pass ? commit_nu : !g.mut) && g.fuse_full && (h->n_partial == 0 || g.ml) &&
-                      !getenv("VMR_ALWAYS_STORE_RHO");
+                      !g.farl && !getenv("VMR_ALWAYS_STORE_RHO");   // (k_far_hist reads rho)
     {
       Prof p(h, lazy ? VMR_KERNEL_RHO_NOSTORE : mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
       if ((rc = sl_launch(h, lazy ? 4 : mode, shs, as))) return rc;
     }
     if (mode != 2) h->rho_stale = lazy;
+    if (g.farl && do_hist && (rc = launch_far(h, 0, nu_in_pass ? (commit_nu ? 1 : 0) : -1))) return rc;
     if ((rc = det_fold(h))) return rc;
   } else {
     Prof p(h, mode == 2 ? VMR_KERNEL_ELBO : mode == 1 ? VMR_KERNEL_RHO_ELBO : VMR_KERNEL_RHO);
@@ -2080,6 +2276,7 @@ static int choose_geo(Geo& g, int ncu, std::string& err) {
   g.Y = 1;    // set by vmr_create once the largest count is known
   g.hc = 0;
   g.two_pass = 0;
+  g.farl = 0;
   g.fuse_full = 0;
   long long T = (long long)g.N * g.N;
   long long gm = (long long)ncu * 8 / g.L; if (gm < 1) gm = 1;
@@ -2255,6 +2452,53 @@ __global__ __launch_bounds__(256) void k_level_hist(const unsigned* __restrict__
   for (int i = threadIdx.x; i < 65; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
+// Geo::farl: (position, entry) of the reports of levels >= g.hc, layer by layer (k_far_collect)
+static int build_far_lists(vmr_ctx* h) {
+  const Geo& g = h->g;
+  const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
+  unsigned long long* cnt = nullptr;
+  CK(hipMalloc(&cnt, 8));
+  unsigned long long* hd = nullptr;
+  std::vector<unsigned long long> hist(65, 0);
+  CK(hipMalloc(&hd, 65 * 8));
+  CK(hipMemsetAsync(hd, 0, 65 * 8, h->stream));
+  hipLaunchKernelGGL(k_level_hist, dim3(1024), dim3(256), 0, h->stream, h->E, h->n_slots, g.Mp, hd);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(hist.data(), hd, 65 * 8, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  CK(hipFree(hd));
+  unsigned long long far = 0;
+  for (int y = std::min(g.hc, 64); y < 65; ++y) far += hist[y];   // (an upper bound: empty slots of a level count too)
+  if (getenv("VMR_VERBOSE")) {
+    fprintf(stderr, "vimure_hip: far lists from level %d; reports per level:", g.hc);
+    for (int y = 0; y < 65; ++y) if (hist[y]) fprintf(stderr, " %d:%llu", y, hist[y]);
+    fprintf(stderr, "\n");
+  }
+  CK(hipMalloc(&h->far_pos, (size_t)(far + 64) * 4));
+  CK(hipMalloc(&h->far_ent, (size_t)(far + 64) * 4));
+  h->far_off.assign(g.L + 1, 0ull);
+  std::vector<unsigned long long> eb(g.L);
+  CK(hipMemcpy(eb.data(), h->ebase, (size_t)g.L * 8, hipMemcpyDeviceToHost));
+  for (int l = 0; l < g.L; ++l) {
+    hipLaunchKernelGGL(k_far_first, dim3((unsigned)std::min<size_t>(8192, (NS + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS + 1),
+                       h->sy + (size_t)l * NS, NS, (unsigned)g.hc * (unsigned)g.Mp);
+    CK(hipGetLastError());
+    CK(hipMemsetAsync(cnt, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_far_collect, dim3((unsigned)std::min<size_t>(8192, (NS + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS + 1), NS,
+                       (unsigned)g.hc * (unsigned)g.Mp, h->far_pos + h->far_off[l], h->far_ent + h->far_off[l], cnt);
+    CK(hipGetLastError());
+    unsigned long long n = 0;
+    CK(hipMemcpyAsync(&n, cnt, 8, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->far_off[l + 1] = h->far_off[l] + n;
+    if (h->far_off[l + 1] > far) { (void)hipFree(cnt); return fail(nullptr, VMR_EHIP, "far lists: more reports than counted"); }
+  }
+  CK(hipFree(cnt));
+  CK(hipMalloc(&h->far_base, (size_t)(g.L + 1) * 8));
+  CK(hipMemcpy(h->far_base, h->far_off.data(), (size_t)(g.L + 1) * 8, hipMemcpyHostToDevice));
+  return VMR_OK;
+}
+
 // the mask lists of at most two reporters, packed by sorted position (SlArgs::rm2)
 __global__ __launch_bounds__(256) void k_rm2(const unsigned* __restrict__ perm, const unsigned* __restrict__ rq, const unsigned short* __restrict__ Rm,
                                              const unsigned long long* __restrict__ rbase, unsigned* __restrict__ out, size_t T, size_t NS, int L) {
@@ -2360,6 +2604,7 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       return false;
     };
     int lv1 = 0, t1 = 256, lvr = 0, tr = 256, lvh = 0, th = 256;
+    bool want_farl = false;
     bool one = best(true, true, 16, lv1, t1);
     if (one && lv1 < want && g.N > 1024) {   // (small networks: one pass whatever the levels -- a sweep there costs its launches)
       // Not every level fits beside the other table.  A report of a level beyond the LDS ones costs its whole 64-tie round the
@@ -2377,10 +2622,18 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       CK(hipFree(hd));
       unsigned long long tot = 0, far = 0;
       for (int y = 0; y < 65; ++y) { tot += hist[y]; if (y >= lv1) far += hist[y]; }
-      if ((double)far > (double)tot / 1024.0) one = false;
+      if ((double)far > (double)tot / 1024.0) {
+        // VMR_FARL=1 (round 4; off by default): still one pass while the far reports are a few per cent -- the pass takes their factors
+        // by formula and leaves their statistics to k_far_hist, which adds them from a compact list of exactly those reports, moved
+        // to the front of every tie's list (k_far_first).  Measured on a BASELINE config-5 layer: 3.44 ms per sweep against 3.53
+        // with two passes, and ELBO sweeps the other way round -- no gain over ten sweeps, so two passes stay.
+        // Not in the deterministic mode (its sums are the integer shadows').
+        if (g.mut && !g.det && env_i("VMR_FARL", 0) && (double)far <= 0.125 * (double)tot) want_farl = true;
+        else one = false;
+      }
     }
     if (getenv("VMR_TWO_PASS")) one = one && !env_i("VMR_TWO_PASS", 0);
-    if (one) { g.yt = g.hc = lv1; h->sp_tpb = h->st_tpb = t1; }
+    if (one) { g.yt = g.hc = lv1; h->sp_tpb = h->st_tpb = t1; g.farl = want_farl ? 1 : 0; }
     else {
       g.two_pass = 1;
       if (!best(true, false, 16, lvr, tr) && !best(true, false, 4, lvr, tr)) { lvr = 0; tr = 256; }
@@ -2397,6 +2650,14 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
     { const int t = env_i("VMR_ST_TPB", h->st_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->st_tpb = t; }
     for (int v = 0; v < 4; ++v) need = std::max(need, sl_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
+    if (g.farl) {
+      // the far lists hold the reports of levels >= g.hc: every variant that adds to H must keep exactly the levels below in LDS
+      bool same = g.hc >= 1 && g.hc < g.Y;
+      for (int v : {0, 3}) same = same && sl_shape(h, v != 3, false, true).hc == g.hc;
+      h->elbo_split = sl_shape(h, true, true, true).hc != g.hc || sl_shape(h, true, true, true).yt != g.yt;   // (the fused ELBO variant also holds the logarithm table)
+      if (!same) g.farl = 0;   // (shapes forced through VMR_YT / VMR_HC / VMR_TPB: the pass then adds the far reports itself, global adds)
+      else { int rcf = build_far_lists(h); if (rcf) return rcf; }
+    }
   } else {
     if (shmem_rho(g, true, false) > 80000) {
       g.two_pass = 1;
@@ -2451,12 +2712,14 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       const SlShape sh = sl_shape(h, false, false, true);
       SlArgs a = sl_args(h, sh, 2);
       rc = sl_launch(h, 3, sh, a);
+      if (rc == VMR_OK && g.farl) rc = launch_far(h, 1, -1);
     }
     if (rc != VMR_OK) { g_create_err = h->err; return rc; }
     CK(hipGetLastError());
     const size_t nit = (size_t)L * g.Y * g.Mp;
     hipLaunchKernelGGL(k_take_counts, dim3((unsigned)std::min<size_t>(1024, (nit + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, h->Cg, g);
     CK(hipGetLastError());
+
   }
   CK(hipStreamSynchronize(h->stream));
   return VMR_OK;
@@ -2899,7 +3162,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3149,12 +3412,12 @@ int vmr_fit_loop(vmr_handle h, int max_iter, double tol, int decision, int cap, 
 // Handles of another kind than the first (K, mutuality, mask kind, report lists in one pass) run their loops one by one.
 static bool batch_steady(const vmr_ctx* h) {
   const Geo& g = h->g;
-  return h->have_state && !h->restored && h->sparse && !g.two_pass && h->h_valid && !h->h_reduced && !h->h_zero &&
+  return h->have_state && !h->restored && h->sparse && !g.two_pass && !g.farl && h->h_valid && !h->h_reduced && !h->h_zero &&
          h->f_valid == (g.fuse_full != 0) && (!g.ml || h->a_valid) && !h->prof;
 }
 static bool batch_kind(const vmr_ctx* h, const vmr_ctx* h0) {
   // (a sweep of such a handle is k_fin_gamma + the pass, + k_fin_rho with an ELBO: the pass sums rho over the mask itself)
-  return h->sparse && !h->g.gen && !h->g.two_pass && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
+  return h->sparse && !h->g.gen && !h->g.two_pass && !h->g.farl && !h->g.det && !h->prof && h->g.fuse_full && (h->n_partial == 0 || h->g.ml) && h->device == h0->device &&
          h->g.K == h0->g.K && h->g.mut == h0->g.mut && (h->all_full != 0) == (h0->all_full != 0);
 }
 namespace {
@@ -3682,6 +3945,14 @@ int vmr_mask_format(vmr_handle h, int* lists, uint64_t* listed) {
   if (!h) return VMR_EINVAL;
   if (lists) *lists = h->rq ? 1 : 0;
   if (listed) *listed = h->n_rm;
+  return VMR_OK;
+}
+
+int vmr_sweep_shape(vmr_handle h, int* passes, int* lds_levels, uint64_t* far_reports) {
+  if (!h) return VMR_EINVAL;
+  if (passes) *passes = h->g.two_pass ? 2 : 1;
+  if (lds_levels) *lds_levels = h->g.gen ? 0 : h->g.hc;
+  if (far_reports) *far_reports = (h->g.farl && !h->far_off.empty()) ? h->far_off.back() : 0ull;
   return VMR_OK;
 }
 

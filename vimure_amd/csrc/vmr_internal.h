@@ -65,6 +65,9 @@ struct Geo {
   int det_shr;  // ... and 2^-det_shr for the ELBO partials (bounded by 64 (sum x + ties K))
   int gen;      // the general kernels (sweep_gen.hip): K > KMAX, or entries too wide for the packed format.  H is then ONE copy
                 // [L][Y][Mp][K] holding every category (no constant C, no deficits), nu and the mask sums go through k_fin_rho / the pass
+  int farl;     // report lists, one pass per sweep although not every level of F / H fits in LDS: the reports of the levels beyond
+                // (y >= hc = yt; a few per cent) are ALSO kept as a compact list (vmr_ctx::far_pos / far_ent); the pass takes their
+                // factors by formula and leaves their statistics to k_far_hist, which follows it
   int wide;     // entries in two words (vmr_ctx::EX): counts beyond 2047 or (max count + 1) * Mp beyond 2^20 table rows
 };
 // fixed point of the deterministic mode: count-weighted sums 2^-g.det_sh; ELBO partials 2^-g.det_shr; sums of rho over ties (< 2^31 ties) 2^-30
@@ -104,6 +107,12 @@ struct vmr_ctx {
   // boundary (vmr_set_state, vmr_get_state, vmr_readout, vmr_sample)
   unsigned* perm = nullptr;    // [L][NS*64] position -> tie (0xffffffff past the last tie)
   unsigned* sy = nullptr;      // [L][NS] highest mirror-count level of a step's reports
+  unsigned* far_pos = nullptr; // Geo::farl: sorted position (layer-local) and entry word of every report of a level beyond the LDS ones,
+  unsigned* far_ent = nullptr; //            layer l at [far_off[l], far_off[l + 1])
+  unsigned long long* far_base = nullptr;   // [L + 1] device copy of far_off
+  std::vector<unsigned long long> far_off;
+  bool elbo_split = false;     // Geo::farl: the fused rho + ELBO variant does not keep g.hc levels in LDS (its logarithm table): an ELBO sweep is
+                               // the plain update pass followed by the ELBO-only pass (same numbers: the stale G_nu, model.py:970)
   uint8_t* cls_p = nullptr;    // [L][T] rcls by position (null when every row is all ones)
   unsigned* Qt_p = nullptr;    // [L][T] Qt by position
   double* nat = nullptr;       // [L][T][K] scratch in tie order for the boundary copies of rho / pr_rho (allocated on first use)
@@ -343,8 +352,9 @@ __device__ __forceinline__ double log_pos(double x) {
 #define SP_TABLE_MATH 1
 #endif
 #define SP_MATH_DOUBLES (64 + 256)
-__device__ __forceinline__ void sp_math_tables(double* xt /*64*/, double* lt /*128 x (1/c, log c)*/, int tid, int nthr) {
+__device__ __forceinline__ void sp_math_tables(double* xt /*64*/, double* lt /*128 x (1/c, log c)*/, int tid, int nthr, bool with_log = true) {
   for (int j = tid; j < 64; j += nthr) xt[j] = exp2((double)j * (1.0 / 64.0));
+  if (!with_log) return;
   for (int i = tid; i < 128; i += nthr) {
     const double c = 0.5 + ((double)i + 0.5) * (1.0 / 256.0);
     lt[2 * i] = 1.0 / c;

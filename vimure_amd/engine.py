@@ -366,6 +366,13 @@ class CaviEngine:
         self._check(self.lib.vmr_mask_format(self._h, C.byref(li), C.byref(n)))
         return ("lists" if li.value else "words"), int(n.value)
 
+    def sweep_shape(self):
+        """(passes over the entries per sweep, mirror-count levels of the statistics kept in LDS, reports in the far lists): the
+        shape vmr_create chose for a sweep of this dataset (vmr_sweep_shape)."""
+        p, lv, n = C.c_int(), C.c_int(), C.c_uint64()
+        self._check(self.lib.vmr_sweep_shape(self._h, C.byref(p), C.byref(lv), C.byref(n)))
+        return int(p.value), int(lv.value), int(n.value)
+
     # -- measurement
     def profile(self, enable=True):
         """HIP events around the engine's kernels; enable=2: only around the passes over the data (not the finalize kernels)."""
