@@ -178,8 +178,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   long long s = step_of((unsigned)wv), sn = step_of((unsigned)(nw + wv));   // the current step and the next
   unsigned ea = 0;    // first slot of the current step
   int R = 0;          // its rounds
-  unsigned ymax = 0;  // its highest mirror-count level
-  unsigned nfar = 0;  // Geo::farl: its leading rounds that may hold reports of the levels beyond the LDS ones (sy, high half)
+  unsigned ymax = 0;  // its sy word: the highest mirror-count level (low half); Geo::farl: the leading rounds that may hold reports of the levels beyond the LDS ones (high half)
   unsigned rgv = 0;   // lanes 0..2: rs[s2], rs[s2 + 1], sy[s2] of the NEXT step (loaded one step earlier)
   StepIn<K> P;        // the prefetched step
 
@@ -224,7 +223,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   if (s < NS) {   // prologue: this wave's first step
     ea = rsl[s];
     R = (int)((rsl[s + 1] - ea) >> 6);
-    { const unsigned syv = syl[s]; ymax = syv & 0xffffu; nfar = syv >> 16; }
+    ymax = syl[s];
     fetch_range(sn < NS ? sn : s);
     fetch_tie(P, s);
     fetch_ent(P, ea, RC<PFK>{});
@@ -414,8 +413,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // (far levels, or more rounds).  row0 / act: the step's first position, this lane's tie exists; ea_c, Rr: its slots and rounds.
   // nf: only the step's rounds 0 .. nf - 1 can hold reports of the levels beyond the LDS ones (Geo::farl: the lists are ordered that way;
   // otherwise every round can)
-  auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned ymax,
-                     const unsigned nf) SL_INL {
+  auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned sy_word) SL_INL {
+    const unsigned ymax = sy_word & 0xffffu, nf = a.farl ? sy_word >> 16 : 0x7fffffffu;
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
@@ -476,7 +475,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // lane needs it.  Rounds past the step's last are empty entries.
         constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
         rounds(RC<GB>{}, [&](const unsigned (&c)[GB], const unsigned j) SL_INL {
-          if (ymax < lim1 || j >= nf) { walk1_near(c, RC<GB>{}, U); return; }   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)
+          if (ymax < lim1 || j >= nf) { walk1_near(c, RC<GB>{}, U); return; }   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)
           double f[GB][K];
           bool fr[GB];
 #pragma unroll
@@ -594,27 +593,17 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
         // beyond the levels go to global memory, per entry and only where some lane needs it
         rounds(RC<1>{}, [&](const unsigned (&c1)[1], const unsigned j) SL_INL {
-          if (j >= nf || lim2 == 0xffffffffu) {   // no report of this round lies beyond the LDS levels: what the straight-line walk does per report
-            const unsigned cn = c1[0], ymn = SL_YM(cn);
-            const double dxn = (double)SL_X(cn);
-            if (a.do_hist) {
-#pragma unroll
-              for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ymn], dxn * r[k], sc_h);
-              if (irr) lds_add(&Hc[ymn], dxn * dfc, sc_h);
-            }
-            if (ELBO) { const double term = dxn * log_tab(elbo_inner(cn, er), lt); if (DET) ie_log += fxm(term, sc_r); else e_log += term; }
-            return;
-          }
           const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
-          const bool fr = ym >= hcm;
+          const bool far_round = j < nf && lim2 != 0xffffffffu;   // (wave-uniform) only such rounds can hold a report beyond the LDS levels
+          const bool fr = far_round && ym >= hcm;
           const double dx = (double)x;
           if (a.do_hist) {
-            if (!fr && x != 0u) {   // (far lanes and empty slots add nothing: zeros added to one common row would serialise them)
+            if (!fr) {   // (far lanes add nothing here: zeros added to one common row would serialise them)
 #pragma unroll
               for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
               if (irr) lds_add(&Hc[ym], dx * dfc, sc_h);   // (wave-uniform: some tie of the step does not sum to 1)
             }
-            if (!a.farl && __any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
+            if (far_round && !a.farl && __any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
               if (fr && x != 0u) {       // table by the grid's last workgroup (nu_far).  (farl: k_far_hist adds them.)
                 if (DET) {
                   unsigned long long* d0 = a.det;
@@ -664,7 +653,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     const bool more = s2 < NS;
     const unsigned ea2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 0) : ea_c;
     const int R2 = more ? (int)(((unsigned)__builtin_amdgcn_readlane((int)rgv, 1) - ea2) >> 6) : 0;
-    const unsigned sy2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u, ym2 = sy2 & 0xffffu, nf2 = sy2 >> 16;
+    const unsigned ym2 = more ? (unsigned)__builtin_amdgcn_readlane((int)rgv, 2) : 0u;
     fetch_range(s3 < NS ? s3 : s);
     fetch_tie(P, more ? s2 : s, RCT == 0 && a.lp0 != 0);   // (sorted order: after a step without reports come only such steps)
     if (RCT >= 0 || PFK <= 8) fetch_ent(P, ea2, RC<NP>{});
@@ -678,7 +667,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         }
       }
     }
-    compute(rct, cur, row0, act, ea_c, Rr, ymax, a.farl ? nfar : 0x7fffffffu);
+    compute(rct, cur, row0, act, ea_c, Rr, ymax);
     // Everything the NEXT step needs was requested at the top of this one: wait for it HERE, before the next step's own
     // requests go out.  (Left to itself the compiler waits at the first use, after those requests -- and where it cannot tell
     // how many requests are younger than the ones it needs it drains them all: memory latency in every step.)  This step's rho
@@ -689,15 +678,15 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     if (RCT >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);   // vmcnt(NST)
     else __builtin_amdgcn_s_waitcnt(0x0F70);                  // (general steps may add global atomics: vmcnt(0))
     // advance
-    s = s2; sn = s3; ea = ea2; R = R2; ymax = ym2; nfar = nf2;
+    s = s2; sn = s3; ea = ea2; R = R2; ymax = ym2;
   };
   // consecutive steps of this wave with the same number of rounds run in one straight-line loop
   auto run = [&](auto rct) SL_INL {
     constexpr int RCT = decltype(rct)::value;
-    do { body(rct); } while (s < NS && R == RCT && ymax < lim_y);
+    do { body(rct); } while (s < NS && R == RCT && (ymax & 0xffffu) < lim_y);
   };
   while (s < NS) {
-    if (R > SL_PF || ymax >= lim_y) { body(RC<-1>{}); continue; }
+    if (R > SL_PF || (ymax & 0xffffu) >= lim_y) { body(RC<-1>{}); continue; }
     switch (R) {
       case 0: run(RC<0>{}); break;
       case 1: run(RC<1>{}); break;
