@@ -72,6 +72,15 @@ struct SlArgs {
   // Geo::farl: reports of levels beyond the LDS ones add nothing to H here (k_far_hist does, from the compact far lists, and
   // finishes nu): no global adds in the pass, and the grid's last workgroup leaves the nu sum standing.
   int farl;
+  // Rounds of level 0 only (two-pass handles, whose statistics pass is bound by its LDS adds): every tie's reports of mirror count
+  // >= 1 come first in its list (k_far_first with the level-0 rows as "near"), and sy's high half holds n1, the first round of a
+  // step in which EVERY tie's report has mirror count 0.  At level 0 the weights are w1 = 1, w2 = 0, so the finalize kernels need
+  // of H[0][m][k] the marginals only: sum_k = C[0][m] - deficits (the constant), sum_m = sum over ties of rho_k times the tie's
+  // counts -- a per-tie product.  From round n1 on the general body adds nothing to the LDS table (but the deficits of irregular
+  // ties) and sums those products into h0s [L][NSLOT][K]; k_level0_spread puts them into H with exactly those marginals.
+  // null: level 0 like every level.  (Masking the level-0 LANES of mixed rounds instead was measured: an LDS instruction costs
+  // the same with half its lanes off.)
+  double* h0s;
   const unsigned* Ez;   // 64 empty entries (the zeroed slack behind E): what the ring of a long step loads past the step's last round
   int elbo_cur;   // ELBO-only pass: the CURRENT G_nu, not the stale one -- nu was not committed since the rho it evaluates (split ELBO sweep of vmr_sweep_local)
 #ifdef SL_DEBUG

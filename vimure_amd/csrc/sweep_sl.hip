@@ -71,6 +71,7 @@ template <int K, bool UPDATE, bool ELBO, bool ALLFULL, bool STORE = true, bool D
 __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const unsigned bx, const unsigned gx) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
+  constexpr bool LV0 = !UPDATE && !ELBO && !DET;   // the variant that takes level-0 rounds without LDS adds (SlArgs::h0s): the statistics pass
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int Mp = g.Mp;
@@ -129,9 +130,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   const float rcp_mp = 1.0f / (float)Mp;
   const double lp0_0 = log(1.0 + eps), lp0_k = log(eps);   // the log prior of a tie nobody reported on (the values k_init_rho_pos stored)
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
-  double accF[K];
+  double accF[K], acc0[K];   // sums over this lane's ties: rho over all-ones mask rows; (SlArgs::h0s) rho_k times the tie's counts in level-0 rounds
 #pragma unroll
-  for (int k = 0; k < K; ++k) accF[k] = 0.0;
+  for (int k = 0; k < K; ++k) { accF[k] = 0.0; acc0[k] = 0.0; }
   // (DET: the same sums as integers -- a lane's ties depend on the tickets its wave drew)
   unsigned long long ie_lin = 0ull, ie_q = 0ull, ie_log = 0ull, iaccF[K];
 #pragma unroll
@@ -415,6 +416,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // otherwise every round can)
   auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned sy_word) SL_INL {
     const unsigned ymax = sy_word & 0xffffu, nf = a.farl ? sy_word >> 16 : 0x7fffffffu;
+    const unsigned n1 = (LV0 && a.h0s) ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::h0s) from this round on every report of the step has mirror count 0
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
@@ -592,12 +594,16 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       } else {
         // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
         // beyond the levels go to global memory, per entry and only where some lane needs it
+        double sx0 = 0.0;   // (SlArgs::h0s) this tie's counts in the rounds of level 0 only
         rounds(RC<1>{}, [&](const unsigned (&c1)[1], const unsigned j) SL_INL {
           const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
           const bool far_round = j < nf && lim2 != 0xffffffffu;   // (wave-uniform) only such rounds can hold a report beyond the LDS levels
           const bool fr = far_round && ym >= hcm;
           const double dx = (double)x;
-          if (a.do_hist) {
+          if (LV0 && a.do_hist && j >= n1) {   // a round of level 0 only: no LDS add but an irregular tie's deficit
+            sx0 += dx;
+            if (irr) lds_add(&Hc[ym], dx * dfc, sc_h);
+          } else if (a.do_hist) {
             if (!fr) {   // (far lanes add nothing here: zeros added to one common row would serialise them)
 #pragma unroll
               for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
@@ -624,6 +630,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
           }
           if (ELBO) { const double term = (double)x * log_tab(elbo_inner(c, er), lt); if (DET) ie_log += fxm(term, sc_r); else e_log += term; }
         });
+        if (LV0 && a.h0s && a.do_hist == 1 && act) {
+#pragma unroll
+          for (int k = 1; k < K; ++k) acc0[k] = fma(r[k], sx0, acc0[k]);
+        }
       }
     }
     if (ELBO && act) {
@@ -852,6 +862,13 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       if (DET) { const unsigned long long v = wave_isum(iaccF[k]); if (lane == 0 && v != 0ull) atomicAdd(&det_F()[k], v); continue; }
       double v = block_sum_n(accF[k], red);
       if (tid == 0) atomicAdd(&a.slotF[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
+    }
+  }
+  if (LV0 && a.h0s && a.do_hist == 1) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      const double v = block_sum_n(acc0[k], red);
+      if (tid == 0 && v != 0.0) atomicAdd(&a.h0s[((size_t)l * NSLOT + (gb % NSLOT)) * K + k], v);
     }
   }
   if (ELBO) {

@@ -1760,7 +1760,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, h->E + h->n_slots, 0};
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, (do_hist == 1 && h->g.two_pass && sh.hc >= 1) ? h->h0s : nullptr, h->E + h->n_slots, 0};   // (level 0 must be among the LDS levels: its deficits go there)
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -1953,6 +1953,37 @@ __global__ __launch_bounds__(1024) void k_far_hist(const unsigned* __restrict__ 
     }
   }
 }
+// SlArgs::h0s: the level-0 statistics of the rounds that took them as per-tie products, put into copy 0 of H with the marginals the
+// finalize kernels read -- sum_m H[0][m][k] = S_k (the pass' sums), sum_k H[0][m][k] = C[0][m] - deficits (rebuilt from the constant
+// as for every level, h_fold_item): H[0][m][k] += C[0][m] S_k / sum_m C[0][m] for k >= 1.  One workgroup per layer; consumes h0s.
+__global__ __launch_bounds__(256) void k_level0_spread(double* Hg, const double* __restrict__ Cg, double* h0s, Geo g) {
+  __shared__ double Sk[KMAX];
+  const int l = blockIdx.x, K = g.K, Mp = g.Mp;
+  if ((int)threadIdx.x < K) {
+    double s = 0.0;
+    for (int sl = 0; sl < NSLOT; ++sl) { s += h0s[((size_t)l * NSLOT + sl) * K + threadIdx.x]; h0s[((size_t)l * NSLOT + sl) * K + threadIdx.x] = 0.0; }
+    const double tot = h0s[(size_t)g.L * NSLOT * K + l];
+    Sk[threadIdx.x] = tot > 0.0 ? s / tot : 0.0;
+  }
+  __syncthreads();
+  double* H0 = Hg + (size_t)l * NH * g.Y * Mp * K;
+  const double* C0 = Cg + (size_t)l * g.Y * Mp;
+  for (int q = threadIdx.x; q < g.M * (K - 1); q += 256) {
+    const int m = q / (K - 1), k = 1 + (q - m * (K - 1));
+    const double c = C0[m];
+    if (c != 0.0 && Sk[k] != 0.0) H0[(size_t)m * K + k] += c * Sk[k];
+  }
+}
+// sum_m C[l][0][m] into h0s' tail (vmr_create, once)
+__global__ __launch_bounds__(256) void k_level0_total(const double* __restrict__ Cg, double* h0s, Geo g) {
+  __shared__ double red[16];
+  const int l = blockIdx.x;
+  double s = 0.0;
+  for (int m = threadIdx.x; m < g.M; m += 256) s += Cg[(size_t)l * g.Y * g.Mp + m];
+  s = block_sum_n(s, red);
+  if (threadIdx.x == 0) h0s[(size_t)g.L * NSLOT * g.K + l] = s;
+}
+
 // nu: -1 = no nu sum in this sweep; 0 = the raw sum to elbo_dev[1]; 1 = nu committed too (as launch_hist's)
 static int launch_far(vmr_ctx* h, int count, int nu) {
   const Geo& g = h->g;
@@ -2069,6 +2100,10 @@ static int launch_hist(vmr_ctx* h, int nu = -1) {
     if (rcs) return rcs;
     HIPCHK(h, hipGetLastError());
     if (g.farl && (rcs = launch_far(h, 0, (nu >= 0 && g.mut) ? nu : -1))) return rcs;
+    if (as.h0s) {
+      hipLaunchKernelGGL(k_level0_spread, dim3(g.L), dim3(256), 0, h->stream, h->Hg, h->Cg, h->h0s, g);
+      HIPCHK(h, hipGetLastError());
+    }
     if ((rcs = det_fold(h))) return rcs;
   } else {
     Prof p(h, VMR_KERNEL_GAMMA_COUNTS);
@@ -2650,6 +2685,21 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     { const int t = env_i("VMR_TPB", h->sp_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->sp_tpb = t; }
     { const int t = env_i("VMR_ST_TPB", h->st_tpb); if (t >= 64 && t <= 1024 && t % 64 == 0) h->st_tpb = t; }
     for (int v = 0; v < 4; ++v) need = std::max(need, sl_shape(h, v != 3, v == 1 || v == 2, v == 0 || v == 1 || v == 3).smem);
+    if (g.two_pass && g.mut && !g.det && g.Y > 1 && !getenv("VMR_NO_LEVEL0")) {
+      // Two passes (a wide reporter dimension): the statistics pass is bound by its LDS adds, and at mirror count 0 -- more than half
+      // of the reports of a mutual network -- none is needed (SlArgs::h0s): every tie's reports of count >= 1 go first, sy's high half
+      // gets the first round of a step that holds level 0 only.
+      const size_t T_ = (size_t)g.N * g.N, NS_ = (T_ + 63) / 64;
+      std::vector<unsigned long long> eb(L);
+      CK(hipMemcpy(eb.data(), h->ebase, (size_t)L * 8, hipMemcpyDeviceToHost));
+      for (int l = 0; l < L; ++l)
+        hipLaunchKernelGGL(k_far_first, dim3((unsigned)std::min<size_t>(8192, (NS_ + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS_ + 1),
+                           h->sy + (size_t)l * NS_, NS_, (unsigned)g.Mp);
+      CK(hipGetLastError());
+      const size_t n0 = (size_t)L * NSLOT * K + L;
+      CK(hipMalloc(&h->h0s, n0 * 8));
+      CK(hipMemsetAsync(h->h0s, 0, n0 * 8, h->stream));
+    }
     if (g.farl) {
       // the far lists hold the reports of levels >= g.hc: every variant that adds to H must keep exactly the levels below in LDS
       bool same = g.hc >= 1 && g.hc < g.Y;
@@ -2719,6 +2769,10 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
     const size_t nit = (size_t)L * g.Y * g.Mp;
     hipLaunchKernelGGL(k_take_counts, dim3((unsigned)std::min<size_t>(1024, (nit + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->Hg, h->Cg, g);
     CK(hipGetLastError());
+    if (h->h0s) {
+      hipLaunchKernelGGL(k_level0_total, dim3(L), dim3(256), 0, h->stream, h->Cg, h->h0s, g);
+      CK(hipGetLastError());
+    }
 
   }
   CK(hipStreamSynchronize(h->stream));
@@ -3162,7 +3216,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
-  void* ptrs[] = {h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->h0s, h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3277,6 +3331,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   h->f_valid = false;
   h->a_valid = false;
   h->h_zero = false; h->a_zero = false;   // (whatever an earlier, possibly failed, sweep left behind)
+  if (h->h0s) HIPCHK(h, hipMemsetAsync(h->h0s, 0, (size_t)h->g.L * NSLOT * h->g.K * 8, h->stream));   // (the slots, not the constants behind them)
   if (h->gen_s1) HIPCHK(h, hipMemsetAsync(h->gen_s1, 0, (size_t)h->g.L * (h->g.Mp + h->g.K) * 8, h->stream));
   return VMR_OK;
 }

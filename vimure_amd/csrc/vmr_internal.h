@@ -111,6 +111,8 @@ struct vmr_ctx {
   unsigned* far_ent = nullptr; //            layer l at [far_off[l], far_off[l + 1])
   unsigned long long* far_base = nullptr;   // [L + 1] device copy of far_off
   std::vector<unsigned long long> far_off;
+  double* h0s = nullptr;       // level-0 rounds without LDS adds (SlArgs::h0s): [L][NSLOT][K] sums over ties of rho_k times the tie's counts in
+                               // such rounds, then [L] sum_m C[l][0][m]
   bool elbo_split = false;     // Geo::farl: the fused rho + ELBO variant does not keep g.hc levels in LDS (its logarithm table): an ELBO sweep is
                                // the plain update pass followed by the ELBO-only pass (same numbers: the stale G_nu, model.py:970)
   uint8_t* cls_p = nullptr;    // [L][T] rcls by position (null when every row is all ones)
