@@ -7,12 +7,26 @@
 __global__ __launch_bounds__(256) void k_sl_keys(const unsigned* __restrict__ cnt, unsigned* __restrict__ keys, unsigned* __restrict__ vals, size_t T) {
   for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (size_t)gridDim.x * 256) { keys[t] = cnt[t]; vals[t] = (unsigned)t; }
 }
+// Second sort key of layers with long lists (most steps then run the sweep's general body): among the ties of equal report count,
+// those with more reports of mirror count >= 1 first -- keys[t] = count << nb | n1.  The ties of a step then agree on n1 too, and
+// with every tie's count->=-1 reports first in its list (k_far_first) the last count - n1 rounds of a step hold mirror count 0
+// only: the statistics pass adds nothing to its LDS table there (SlArgs::h0s).  rpl: scanned counts; E: the layer's entries, tie-major.
+__global__ __launch_bounds__(256) void k_sl_level_keys(unsigned* __restrict__ keys, const unsigned* __restrict__ rpl, const unsigned* __restrict__ E,
+                                                       size_t T, unsigned rows0, int nb) {
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (size_t)gridDim.x * 256) {
+    const unsigned r0 = rpl[t], n = rpl[t + 1] - r0;
+    unsigned n1 = 0;
+    for (unsigned r = 0; r < n; ++r) n1 += SL_YM(E[(size_t)r0 + r]) >= rows0 ? 1u : 0u;
+    keys[t] = (n << nb) | n1;
+  }
+}
 // per step: slots = 64 * (count of the step's first = most reported tie); the sorted order padded to whole steps
+// (nb: low bits of a key that hold the second sort key, k_sl_level_keys)
 __global__ __launch_bounds__(256) void k_sl_steps(const unsigned* __restrict__ keys_sorted, const unsigned* __restrict__ vals_sorted,
-                                                  unsigned* __restrict__ sz, unsigned* __restrict__ perm, size_t T, size_t NS) {
+                                                  unsigned* __restrict__ sz, unsigned* __restrict__ perm, size_t T, size_t NS, int nb) {
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < NS * 64; q += (size_t)gridDim.x * 256) {
     perm[q] = q < T ? vals_sorted[q] : 0xffffffffu;
-    if ((q & 63) == 0) sz[q >> 6] = 64u * keys_sorted[q];
+    if ((q & 63) == 0) sz[q >> 6] = 64u * (keys_sorted[q] >> nb);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) sz[NS] = 0u;
 }
@@ -109,19 +123,36 @@ int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long l
   size_t tb = 0;
   int bits = 1;
   while (bits < 32 && (1ull << bits) <= (unsigned long long)g.M) ++bits;   // a tie holds at most M reports
-  CKS(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, vals2, (int)T, 0, bits, h->stream));
+  // (layers of long lists: a second key, k_sl_level_keys -- packed entries of a mutual network only)
+  const bool level_keys_ok = !wide && g.mut && 2 * bits <= 30 && !getenv("VMR_NO_LEVEL_SORT");
+  CKS(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, vals2, (int)T, 0, level_keys_ok ? 2 * bits : bits, h->stream));
   CKS(hipMalloc(&tmp, tb ? tb : 8));
   const unsigned tgrid = (unsigned)std::min<size_t>(8192, (T + 255) / 256), sgrid = (unsigned)std::min<size_t>(8192, (NS + 3) / 4);
+  if (!etmp_all) {
+    unsigned long long nlmax = 0;
+    for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
+    CKS(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
+    if (wide) CKS(hipMalloc(&etmp2, ((size_t)nlmax + 64) * 4));
+  }
+  unsigned long long off1 = 0;
   for (int l = 0; l < L; ++l) {
     unsigned* rpl = rp + (size_t)l * n;
     unsigned* rsl = h->rs + (size_t)l * (NS + 1);
-    hipLaunchKernelGGL(k_sl_keys, dim3(tgrid), dim3(256), 0, h->stream, rpl, keys, vals, T);
-    CKS(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, vals2, (int)T, 0, bits, h->stream));   // (stable: equal counts keep tie order)
-    hipLaunchKernelGGL(k_sl_steps, dim3((unsigned)std::min<size_t>(8192, (NS * 64 + 255) / 256)), dim3(256), 0, h->stream, keys2, vals2, rsl,
-                       h->perm + (size_t)l * NS * 64, T, NS);
-    CKS(hipGetLastError());
+    const bool by_level = level_keys_ok && (double)nl[l] > (double)SL_PF * (double)T;
+    const int nb = by_level ? bits : 0;
     int rc;
-    if ((rc = scan_u32(h, rsl, bsum, NS + 1)) || (rc = scan_u32(h, rpl, bsum, n))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(k_sl_keys, dim3(tgrid), dim3(256), 0, h->stream, rpl, keys, vals, T);
+    if (by_level) {
+      if ((rc = scan_u32(h, rpl, bsum, n))) { cleanup(); return rc; }
+      if (!etmp_all) (*fill)(l, rpl, etmp, etmp2);
+      hipLaunchKernelGGL(k_sl_level_keys, dim3(tgrid), dim3(256), 0, h->stream, keys, rpl, etmp_all ? etmp_all + off1 : etmp, T, (unsigned)g.Mp, nb);
+    }
+    CKS(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, vals2, (int)T, 0, bits + nb, h->stream));   // (stable: equal keys keep tie order)
+    hipLaunchKernelGGL(k_sl_steps, dim3((unsigned)std::min<size_t>(8192, (NS * 64 + 255) / 256)), dim3(256), 0, h->stream, keys2, vals2, rsl,
+                       h->perm + (size_t)l * NS * 64, T, NS, nb);
+    CKS(hipGetLastError());
+    if ((rc = scan_u32(h, rsl, bsum, NS + 1)) || (!by_level && (rc = scan_u32(h, rpl, bsum, n)))) { cleanup(); return rc; }
+    off1 += nl[l];
   }
   CKS(hipStreamSynchronize(h->stream));
   std::vector<unsigned> slots(L);
@@ -139,12 +170,6 @@ int sl_place_entries(vmr_ctx* h, unsigned* rp, const std::vector<unsigned long l
   if (wide) {
     CKS(hipMalloc(&h->EX, ((size_t)h->n_slots + SL_SLACK) * 4));
     CKS(hipMemsetAsync(h->EX + h->n_slots, 0, (size_t)SL_SLACK * 4, h->stream));
-  }
-  if (!etmp_all) {
-    unsigned long long nlmax = 0;
-    for (int l = 0; l < L; ++l) nlmax = std::max(nlmax, nl[l]);
-    CKS(hipMalloc(&etmp, ((size_t)nlmax + 64) * 4));
-    if (wide) CKS(hipMalloc(&etmp2, ((size_t)nlmax + 64) * 4));
   }
   unsigned long long off = 0;
   for (int l = 0; l < L; ++l) {
