@@ -81,6 +81,8 @@ struct SlArgs {
   // null: level 0 like every level.  (Masking the level-0 LANES of mixed rounds instead was measured: an LDS instruction costs
   // the same with half its lanes off.)
   double* h0s;
+  int lv0r;   // sy's high half holds that round (the handle's lists are ordered for it): the rho update takes a level-0 round's factors
+              // as E log theta_m + E log lambda_k -- one table read per report instead of K
   const unsigned* Ez;   // 64 empty entries (the zeroed slack behind E): what the ring of a long step loads past the step's last round
   int elbo_cur;   // ELBO-only pass: the CURRENT G_nu, not the stale one -- nu was not committed since the rho it evaluates (split ELBO sweep of vmr_sweep_local)
 #ifdef SL_DEBUG

@@ -476,7 +476,17 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // others read row 0 with x = 0); lanes whose row lies beyond take the table's formula, per entry and only where some
         // lane needs it.  Rounds past the step's last are empty entries.
         constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
+        const unsigned n1u = a.lv0r ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::lv0r) from this round on every report of the step has mirror count 0
+        double sl0 = 0.0, sx1 = 0.0;
         rounds(RC<GB>{}, [&](const unsigned (&c)[GB], const unsigned j) SL_INL {
+          if (j >= n1u) {   // level 0: w1 = 1, the factor is E log theta_m + E log lambda_k (the row index is m)
+            double l0[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) l0[u] = Lth[SL_YM(c[u])];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { const double dx = (double)SL_X(c[u]); sl0 = fma(dx, l0[u], sl0); sx1 += dx; }
+            return;
+          }
           if (ymax < lim1 || j >= nf) { walk1_near(c, RC<GB>{}, U); return; }   // (these reports all lie in the LDS levels of F: known per step, and per round where the far ones come first)
           double f[GB][K];
           bool fr[GB];
@@ -506,6 +516,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             }
           }
         });
+        if (a.lv0r) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) U[k] += fma(Lla[k], sx1, sl0);
+        }
       }
       // ---- per-tie update from the finished sums
       double aa[K];

@@ -1760,7 +1760,7 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, (do_hist == 1 && h->g.two_pass && sh.hc >= 1) ? h->h0s : nullptr, h->E + h->n_slots, 0};   // (level 0 must be among the LDS levels: its deficits go there)
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, (do_hist == 1 && h->g.two_pass && sh.hc >= 1) ? h->h0s : nullptr, (h->h0s && h->g.two_pass && !getenv("VMR_NO_LV0R")) ? 1 : 0, h->E + h->n_slots, 0};   // (level 0 must be among the LDS levels: its deficits go there)
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
