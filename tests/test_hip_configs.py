@@ -213,6 +213,47 @@ def test_long_steps_two_categories(mask, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("mask", ["ones", "random"])
+def test_two_passes_level_zero_rounds_with_and_without_mask(mask, monkeypatch):
+    """The statistics pass of a two-pass handle with long lists: ties sorted by (reports, reports of mirror count >= 1), the
+    level-0 rounds of a step add nothing to the LDS table (their marginals go through per-tie products, SlArgs::h0s) and the rho
+    pass takes their factors from the per-reporter table -- K = 3, 640 reporters, two passes forced on a small network, all-ones
+    and partial mask rows, against the coordinate-list oracle; VMR_NO_LEVEL0 / VMR_NO_LEVEL_SORT give the same numbers."""
+    from oracle import cavi_coo
+    from vimure_amd import CaviEngine
+    monkeypatch.setenv("VMR_FORMAT", "sparse")
+    monkeypatch.setenv("VMR_TWO_PASS", "1")
+    L, N, M, K = 2, 90, 640, 3
+    g = np.random.RandomState(21)
+    X = ((g.rand(L, N, N, M) < 0.03) * g.randint(1, 4, size=(L, N, N, M))).astype(np.uint8)
+    X = np.maximum(X, (np.transpose(X, (0, 2, 1, 3)) > 0) * (g.rand(L, N, N, M) < 0.5) * g.randint(1, 3, size=(L, N, N, M))).astype(np.uint8)   # mirrored reports: levels >= 1
+    R = None if mask == "ones" else (g.rand(L, N, N, M) < 0.7).astype(np.uint8)
+    sx = np.nonzero(X)
+    elbos = {}
+    for variant in ("default", "no_level0", "no_level_sort"):
+        if variant == "no_level0":
+            monkeypatch.setenv("VMR_NO_LEVEL0", "1")
+        elif variant == "no_level_sort":
+            monkeypatch.delenv("VMR_NO_LEVEL0")
+            monkeypatch.setenv("VMR_NO_LEVEL_SORT", "1")
+        eng = CaviEngine(X, R, K=K, mutuality=True, device=0)
+        assert eng.data_format()[0] == "sparse" and eng.sweep_shape()[0] == 2
+        sum_x, cov = eng.data_stats()
+        init = _host_state(L, N, M, K, True, 6, sum_x, cov)
+        c = cavi_coo.CooRef((sx, X[sx]), None if R is None else np.nonzero(R), (L, N, N, M), K, True, PRI, *init)
+        eng.set_priors(*PRI)
+        eng.set_state(*init)
+        for it in range(1, 4):
+            c.cavi_step()
+            e = eng.step(1, want_elbo=True)
+            e_cpu = c.elbo()
+            assert abs(e - e_cpu) <= 1e-9 * abs(e_cpu), (variant, it, e, e_cpu)
+        _assert_state(eng.get_state(), c, e, e_cpu)
+        elbos[variant] = e
+        eng.close()
+    assert max(elbos.values()) - min(elbos.values()) <= 1e-9 * abs(elbos["default"])
+
+
 def test_config5_layer_at_stated_size():
     """BASELINE configs[4] as stated -- L=8, N=8000, M=1000, K=3, one layer per GPU: ONE GPU's share (a 64 GB layer generated on
     the device, 1.2 G reports) through a sweep, checked by properties that need no 200-second oracle build:
