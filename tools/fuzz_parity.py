@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): random shapes, K, mutuality, mask kinds, count ranges and engine shapes against the
-coordinate-list oracle -- three sweeps with the ELBO each, state compared at the end.  `python tools/fuzz_parity.py [n] [seed] [wide]`."""
+coordinate-list oracle -- three sweeps with the ELBO each, state compared at the end.  `python tools/fuzz_parity.py [n] [seed] [wide|long]`.
+long: many reports per tie with mirrored counts (the sweep's general body, ties sorted by the second key, level-0 rounds), two passes
+and far lists forced at random."""
 import os
 import sys
 import time
@@ -11,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PRI = (0.1, 0.1, 10.0, 10.0, 0.5, 1.0)
 
 
-def one(case, g, wide=False):
+def one(case, g, wide=False, long_=False):
     """wide: the inputs beyond the specialised kernels -- K up to 70 (the reference's default K = max(X) + 1 gives such K) and counts
     beyond 11 bits / table rows beyond 2^20 (two-word entries) -- which the general kernels (csrc/sweep_gen.hip) take."""
     from oracle import cavi_coo
@@ -23,7 +25,19 @@ def one(case, g, wide=False):
     mut = bool(g.rand() < 0.7)
     dens = float(g.choice([0.01, 0.05, 0.2, 0.5]))
     xmax = int(g.choice([1, 3, 10, 63] if not wide else [3, 40, 120, 255, 3000]))
+    if long_:   # 9..40 reports per tie, many of them mirrored (levels >= 1), some ties reported by nearly everybody
+        N = int(g.choice([17, 33, 64, 65, 90]))
+        M = int(g.choice([64, 65, 130, 300, 640]))
+        K = int(g.choice([2, 2, 3, 3, 4, 5, 8]))
+        mut = bool(g.rand() < 0.85)
+        dens = float(g.choice([10, 14, 19, 30, 40])) / M
+        xmax = int(g.choice([1, 2, 3, 6]))
     X = ((g.rand(L, N, N, M) < dens) * g.randint(1, xmax + 1, size=(L, N, N, M))).astype(np.uint8 if xmax <= 255 else np.int32)
+    if long_:
+        mir = (np.transpose(X, (0, 2, 1, 3)) > 0) & (g.rand(L, N, N, M) < float(g.choice([0.0, 0.3, 0.6])))
+        X = np.maximum(X, mir * g.randint(1, xmax + 1, size=(L, N, N, M))).astype(X.dtype)
+        heavy = g.rand(L, N, N) < 0.01
+        X[heavy] = np.maximum(X[heavy], (g.rand(int(heavy.sum()), M) < 0.9) * g.randint(1, xmax + 1, size=(int(heavy.sum()), M))).astype(X.dtype)
     mk = g.choice(["ones", "none", "random", "sparse", "self"])
     if mk == "none":
         R = None
@@ -48,7 +62,26 @@ def one(case, g, wide=False):
         env.update({"VMR_TWO_PASS": str(int(g.rand() < 0.5)), "VMR_YT": str(int(g.randint(0, 4))), "VMR_HC": str(int(g.randint(0, 4)))})
     if g.rand() < 0.3:
         env["VMR_TPB"] = str(int(g.choice([64, 128, 256, 512, 1024])))
-    old = {k: os.environ.get(k) for k in ("VMR_FORMAT", "VMR_ST_TPB", "VMR_TWO_PASS", "VMR_YT", "VMR_HC", "VMR_TPB")}
+    if long_:
+        env["VMR_FORMAT"] = "sparse"
+        env.pop("VMR_YT", None); env.pop("VMR_HC", None)
+        r = g.rand()
+        if r < 0.5:
+            env["VMR_TWO_PASS"] = "1"
+            if g.rand() < 0.3:
+                env["VMR_HC"] = str(int(g.randint(1, 4)))
+        elif r < 0.7:
+            env["VMR_TWO_PASS"] = "0"
+        else:
+            env.pop("VMR_TWO_PASS", None)
+        if g.rand() < 0.2:
+            env["VMR_NO_LEVEL_SORT"] = "1"
+        if g.rand() < 0.15:
+            env["VMR_NO_LEVEL0"] = "1"
+        if g.rand() < 0.15:
+            env["VMR_NO_LV0R"] = "1"
+    old = {k: os.environ.get(k) for k in ("VMR_FORMAT", "VMR_ST_TPB", "VMR_TWO_PASS", "VMR_YT", "VMR_HC", "VMR_TPB", "VMR_NO_LEVEL_SORT", "VMR_NO_LEVEL0",
+                                          "VMR_NO_LV0R")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -119,9 +152,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
     g = np.random.RandomState(seed)
     t0 = time.time()
-    bad = sum(0 if one(i, g, wide) else 1 for i in range(n))
+    bad = sum(0 if one(i, g, wide, long_) else 1 for i in range(n))
     print(f"{n} cases, {bad} failed, {time.time() - t0:.0f} s", flush=True)
     sys.exit(1 if bad else 0)
 
