@@ -177,3 +177,37 @@ def test_groups_on_several_lanes_give_the_same_fits():
         assert [(r["seed"], r["iters"], r["converged"]) for r in a] == [(r["seed"], r["iters"], r["converged"]) for r in b]
         np.testing.assert_allclose([r["elbo"] for r in b], [r["elbo"] for r in a], rtol=1e-10)
         np.testing.assert_allclose([r["nu"] for r in b], [r["nu"] for r in a], rtol=1e-9)
+
+
+@pytest.mark.parametrize("K,L", [(2, 1), (3, 2)])
+def test_graph_replay_of_sweeps_equals_the_eager_loop(K, L, monkeypatch):
+    """VMR_GRAPH=1: the plain sweeps of vmr_step / the fit loop replayed as hipGraphs (up to 9 per launch, rho unwritten inside
+    them) give the trace, the ELBO and the state of the same loop queued launch by launch -- and, across two realisations on one
+    handle, graphs do not outlive vmr_set_state."""
+    X, R = _village(70, 91, K=K, L=L)
+    res = {}
+    for mode in ("eager", "graph"):
+        if mode == "graph":
+            monkeypatch.setenv("VMR_GRAPH", "1")
+        eng = _engine_with_state(X, R, K, 17)
+        a = eng.fit_loop(41, 0.1, 1)
+        eng.step(13)
+        e1 = eng.step(7, want_elbo=True)
+        st1 = eng.get_state(rho=True)
+        # a second realisation on the same handle: another state, the same calls
+        from bench import draw_state
+        sum_x, cov = eng.data_stats()
+        host, pr = draw_state(dict(L=int(X.shape[0]), N=int(X.shape[1]), M=int(X.shape[3]), K=K, mutuality=True), 18, sum_x, cov)
+        eng.set_state(host.gamma_shp, host.gamma_rte, host.phi_shp, host.phi_rte, host.nu_shp, host.nu_rte, pr)
+        b = eng.fit_loop(31, 0.1, 1)
+        st2 = eng.get_state(rho=True)
+        res[mode] = (a, e1, st1, b, st2)
+        eng.close()
+    (a0, e0, s0, b0, t0), (a1, e1, s1, b1, t1) = res["eager"], res["graph"]
+    for x, y in ((a0, a1), (b0, b1)):
+        assert [r[0] for r in x[0]] == [r[0] for r in y[0]] and x[2] == y[2] and x[3] == y[3]
+        np.testing.assert_allclose([r[1] for r in y[0]], [r[1] for r in x[0]], rtol=1e-10)
+    assert abs(e0 - e1) <= 1e-10 * abs(e0)
+    for u, v in ((s0, s1), (t0, t1)):
+        for k in ("gamma_shp", "gamma_rte", "phi_shp", "phi_rte", "nu_shp", "rho"):
+            np.testing.assert_allclose(v[k], u[k], rtol=1e-9, atol=1e-12, err_msg=k)

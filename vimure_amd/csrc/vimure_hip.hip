@@ -2362,7 +2362,7 @@ static int create_ctx(vmr_ctx** out, hipDeviceProp_t* prop, int device, int L, i
   CK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   h->ncu = prop->multiProcessorCount;
   h->serial = getenv("VMR_SERIAL") != nullptr;
-  h->use_graphs = getenv("VMR_GRAPH") != nullptr;   // off by default, see vmr_ctx::graphs
+  h->use_graphs = getenv("VMR_GRAPH") ? atoi(getenv("VMR_GRAPH")) != 0 : false;   // (off by default: see vmr_ctx::graphs)
   { const char* dv = getenv("VMR_DETERMINISTIC"); g.det = (dv && atoi(dv) != 0) ? 1 : 0; g.det_sh = 0; g.det_shr = 0; }   // sorted report lists unless the older step layout is asked for
   const size_t rows = (size_t)L * N * N;
   CK(hipMalloc(&h->cov, rows));
@@ -2492,8 +2492,9 @@ static int build_far_lists(vmr_ctx* h) {
   const Geo& g = h->g;
   const size_t T = (size_t)g.N * g.N, NS = (T + 63) / 64;
   unsigned long long* cnt = nullptr;
-  CK(hipMalloc(&cnt, 8));
   unsigned long long* hd = nullptr;
+  struct Tmp { unsigned long long*& a; unsigned long long*& b; ~Tmp() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } tmp_guard{cnt, hd};   // (freed on every way out)
+  CK(hipMalloc(&cnt, 8));
   std::vector<unsigned long long> hist(65, 0);
   CK(hipMalloc(&hd, 65 * 8));
   CK(hipMemsetAsync(hd, 0, 65 * 8, h->stream));
@@ -2501,7 +2502,6 @@ static int build_far_lists(vmr_ctx* h) {
   CK(hipGetLastError());
   CK(hipMemcpyAsync(hist.data(), hd, 65 * 8, hipMemcpyDeviceToHost, h->stream));
   CK(hipStreamSynchronize(h->stream));
-  CK(hipFree(hd));
   unsigned long long far = 0;
   for (int y = std::min(g.hc, 64); y < 65; ++y) far += hist[y];   // (an upper bound: empty slots of a level count too)
   if (getenv("VMR_VERBOSE")) {
@@ -2526,9 +2526,8 @@ static int build_far_lists(vmr_ctx* h) {
     CK(hipMemcpyAsync(&n, cnt, 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     h->far_off[l + 1] = h->far_off[l] + n;
-    if (h->far_off[l + 1] > far) { (void)hipFree(cnt); return fail(nullptr, VMR_EHIP, "far lists: more reports than counted"); }
+    if (h->far_off[l + 1] > far) return fail(nullptr, VMR_EHIP, "far lists: more reports than counted");
   }
-  CK(hipFree(cnt));
   CK(hipMalloc(&h->far_base, (size_t)(g.L + 1) * 8));
   CK(hipMemcpy(h->far_base, h->far_off.data(), (size_t)(g.L + 1) * 8, hipMemcpyHostToDevice));
   return VMR_OK;
@@ -3215,7 +3214,7 @@ void vmr_destroy(vmr_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
+  for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.ex);
   void* ptrs[] = {h->h0s, h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
@@ -3276,6 +3275,7 @@ int vmr_set_priors(vmr_handle h, const double* alpha_theta, const double* beta_t
   return VMR_OK;
 }
 
+static void drop_graphs(vmr_ctx* h);
 int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte, const double* phi_shp,
                   const double* phi_rte, double nu_shp, double nu_rte, const double* pr_rho, int pr_rho_on_device) {
   if (!h || !gamma_shp || !gamma_rte || !phi_shp || !phi_rte || !pr_rho) return fail(h, VMR_EINVAL, "NULL state array");
@@ -3324,6 +3324,7 @@ int vmr_set_state(vmr_handle h, const double* gamma_shp, const double* gamma_rte
   // may still be pending on the handle's own stream when it returns)
   HIPCHK(h, hipMemsetAsync(h->slotF, 0, (size_t)g.L * NSLOT * g.K * 8, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  drop_graphs(h);   // (a realisation's arguments may differ: SlArgs::lp0)
   h->have_state = true;
   h->restored = false;
   h->rho_stale = false;
@@ -3349,17 +3350,33 @@ static int sweep(vmr_ctx* h, int mode, bool store = true) {
   return launch_rho(h, mode, true, false, store);
 }
 
-// After a committed sweep the handle is in a fixed point of its bookkeeping: the next sweep is the same three or four
-// launches with the same arguments.  Such sweeps are captured once (per count n) and replayed as one graph launch.
+// After a committed sweep the handle is in a fixed point of its bookkeeping: the next sweep is the same two or three launches with
+// the same arguments.  Such sweeps are captured once (per count, kind of last sweep and bookkeeping state) and replayed as one
+// graph launch.
 static bool sweep_steady(const vmr_ctx* h) {
-  return h->have_state && h->h_valid && h->h_reduced && !h->h_zero && h->f_valid == (h->g.fuse_full != 0) && (!h->g.ml || h->a_valid) && !h->prof;
+  return h->have_state && h->h_valid && !h->h_zero && h->f_valid == (h->g.fuse_full != 0) && (!h->g.ml || h->a_valid) && !h->prof;
 }
-static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
-  for (auto& e : h->graphs) if (e.first == n) { *out = e.second; return VMR_OK; }
+static unsigned state_sig(const vmr_ctx* h) {
+  return (h->h_valid ? 1u : 0u) | (h->h_reduced ? 2u : 0u) | (h->h_zero ? 4u : 0u) | (h->f_valid ? 8u : 0u) | (h->a_valid ? 16u : 0u) | (h->a_zero ? 32u : 0u) |
+         (h->rho_stale ? 64u : 0u);
+}
+static void state_set(vmr_ctx* h, unsigned s) {
+  h->h_valid = s & 1u; h->h_reduced = s & 2u; h->h_zero = s & 4u; h->f_valid = s & 8u; h->a_valid = s & 16u; h->a_zero = s & 32u; h->rho_stale = s & 64u;
+}
+static void drop_graphs(vmr_ctx* h) {
+  for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.ex);
+  h->graphs.clear();
+}
+// n plain sweeps from the handle's present state, the last one with (lazy_last) or without leaving rho unwritten
+static int graph_for(vmr_ctx* h, int n, bool lazy_last, const vmr_ctx::GraphEntry** out) {
+  const unsigned sig0 = state_sig(h);
+  for (auto& e : h->graphs) if (e.n == n && e.lazy_last == lazy_last && e.sig0 == sig0) { *out = &e; return VMR_OK; }
   hipGraph_t gr = nullptr;
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = VMR_OK;
-  for (int i = 0; i < n && rc == VMR_OK; ++i) rc = sweep(h, 0);
+  for (int i = 0; i < n && rc == VMR_OK; ++i) rc = sweep(h, 0, i == n - 1 ? !lazy_last : false);   // (queues nothing: the launches are recorded)
+  const unsigned sig1 = state_sig(h);
+  state_set(h, sig0);   // nothing ran yet
   hipError_t e = hipStreamEndCapture(h->stream, &gr);
   if (rc != VMR_OK || e != hipSuccess || !gr) {
     if (gr) (void)hipGraphDestroy(gr);
@@ -3372,8 +3389,8 @@ static int graph_for(vmr_ctx* h, int n, hipGraphExec_t* out) {
   e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
   (void)hipGraphDestroy(gr);
   if (e != hipSuccess) { (void)hipGetLastError(); h->use_graphs = false; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return VMR_EHIP; }
-  h->graphs.push_back({n, ex});
-  *out = ex;
+  h->graphs.push_back({n, lazy_last, sig0, sig1, ex});
+  *out = &h->graphs.back();
   return VMR_OK;
 }
 
@@ -3394,12 +3411,14 @@ static int step_n(vmr_ctx* h, int n_iters, double* elbo_out, bool store_last) {
   int it = 0;
   const int plain = elbo_out ? n_iters - 1 : n_iters;   // sweeps without an ELBO
   if (h->use_graphs && plain >= 2) {
-    if (!sweep_steady(h)) { if ((rc = sweep(h, 0))) return rc; it = 1; }
+    if (!sweep_steady(h)) { if ((rc = sweep(h, 0, false))) return rc; it = 1; }   // (more sweeps follow: its rho is overwritten unread)
     while (h->use_graphs && sweep_steady(h) && plain - it >= 2) {
       const int n = (plain - it >= 9) ? 9 : (plain - it);   // the fit loop asks for 9 between two ELBO checks (model.py:1036)
-      hipGraphExec_t ex = nullptr;
-      if (graph_for(h, n, &ex) != VMR_OK) break;   // capture failed: the eager loop below takes over
-      HIPCHK(h, hipGraphLaunch(ex, h->stream));
+      const bool ends = it + n == n_iters;   // the call's last sweep is in this graph (no ELBO sweep behind it)
+      const vmr_ctx::GraphEntry* ge = nullptr;
+      if (graph_for(h, n, !(ends && store_last), &ge) != VMR_OK) break;   // capture failed: the eager loop below takes over
+      HIPCHK(h, hipGraphLaunch(ge->ex, h->stream));
+      state_set(h, ge->sig1);
       it += n;
     }
   }

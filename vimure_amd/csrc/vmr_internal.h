@@ -129,11 +129,15 @@ struct vmr_ctx {
   // state
   double *rho = nullptr, *logpr = nullptr;
   double* par = nullptr;       // parameter block, see P_* offsets
-  // steady-state sweeps as hipGraphs (vmr_step; env VMR_GRAPH=1).  Measured on the Karnataka-shaped batch (48 fits, 8 host
-  // threads): 22.3 fits/s with graphs against 22.9 without -- the dependent 10 us kernels of a sweep, not the launch calls,
-  // set a small fit's pace -- and a capture is invalidated when another host thread creates or destroys a handle meanwhile
-  // (hipMalloc / hipFree during capture), so the eager path is the default.
-  std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (sweeps in the graph, executable)
+  // Steady-state sweeps as hipGraphs (vmr_step and the fit loop: up to 9 plain sweeps per launch; env VMR_GRAPH=1).  Off by default:
+  // measured at BASELINE config 3 (round 4, with the unwritten rho inside the graphs) 5797-5959 iterations/s replayed against
+  // 5882-5906 queued launch by launch -- the two launches of a sweep are not what it waits for; on the Karnataka-shaped batch (48
+  // fits, 8 host threads) 22.3 fits/s against 22.9 -- and a capture is invalidated when another host thread creates or destroys a
+  // handle meanwhile (hipMalloc / hipFree during capture; step_n then falls back to the eager loop for good).
+  // A graph is the sweeps' launches with their ARGUMENTS: keyed by the count, by whether its last sweep leaves rho unwritten and by
+  // the handle's bookkeeping state at capture (sig0; sig1 = the state it leaves), dropped whenever vmr_set_state may change an argument.
+  struct GraphEntry { int n; bool lazy_last; unsigned sig0, sig1; hipGraphExec_t ex; };
+  std::vector<GraphEntry> graphs;
   bool use_graphs = false;
   unsigned long long* det_buf = nullptr;   // deterministic mode: integer shadows of H (one copy), the mask sums, the ELBO partials, the nu share
   double* fr_slots = nullptr;              // ... and k_fin_rho's per-workgroup partial sums [L * FR_G][2]
