@@ -656,7 +656,7 @@ int gen_gamma(vmr_ctx* h, bool with_phi) {
   {
     Prof p(h, VMR_KERNEL_FINALIZE);
     const int nb = gen_hsum_blocks(h), ext = nb > 1 ? 1 : 0;
-    const int s1_lds = (!ext && (size_t)g.Mp * 8 <= 40 * 1024) ? 1 : 0;
+    const int s1_lds = (!ext && (size_t)(5 * g.K + g.Mp) * 8 <= 48 * 1024) ? 1 : 0;   // (within the default dynamic-LDS limit, the K-sized arrays included)
     double* slotA = (h->n_partial > 0 || !h->a_zero) ? h->slotA : nullptr;
     if (ext) hipLaunchKernelGGL(k_gen_hsum, dim3(g.L * nb), dim3(1024), (size_t)g.K * 8, h->stream, h->par, h->Hg, h->gen_s1, 0, 0, nb, g);
     hipLaunchKernelGGL(k_fin_gamma_gen, dim3(g.L), dim3(1024), (size_t)5 * g.K * 8 + (s1_lds ? (size_t)g.Mp * 8 : 0), h->stream, h->par, h->Hg, slotA,
