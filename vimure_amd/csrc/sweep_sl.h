@@ -98,7 +98,10 @@ struct SlUnit { SlArgs a; Geo g; int blk0, nblk; };
 // ELBO variants carry the logarithms' on top, so the kernels are compiled for fewer, fatter waves as K grows -- no variant
 // spills (profiles/r03_kernel_resources.md).  Largest workgroup / waves per SIMD the kernel<K, ., ELBO, .> is compiled for:
 // (allfull: every mask row is all ones -- the variants without the mask code need a few registers fewer)
-constexpr bool sl_light(int K, bool elbo, bool allfull, bool update) { return !elbo && allfull && (K <= 2 || (!update && K <= 4)); }   // fits 128 registers
+#ifndef SL_LIGHT_UPD_K   // largest K whose all-ones update variant is compiled for 128 registers (4 waves per SIMD, 1024 threads)
+#define SL_LIGHT_UPD_K 2
+#endif
+constexpr bool sl_light(int K, bool elbo, bool allfull, bool update) { return !elbo && allfull && (K <= SL_LIGHT_UPD_K || (!update && K <= 4)); }   // fits 128 registers
 #ifndef SL_ELBO3   // K = 2 ELBO variants at 3 waves per SIMD (168 registers, ~20 dwords spilled): 0.259 against 0.282 ms per config-3 launch at 2
 #define SL_ELBO3 1
 #endif
