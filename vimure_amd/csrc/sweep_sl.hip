@@ -72,6 +72,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int PFK = sl_pf(K);   // rounds prefetched one step ahead
   constexpr bool LV0 = !UPDATE && !ELBO && !DET;   // the variant that takes level-0 rounds without LDS adds (SlArgs::h0s): the statistics pass
+  constexpr bool LV0R = UPDATE && K >= 3;           // the variants whose general body reads one table value per level-0 report (SlArgs::lv0r);
+                                                    // not K = 2: the few registers it takes cost BASELINE config 3's variants 1 %
   const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int Mp = g.Mp;
@@ -99,8 +101,13 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   const size_t T = (size_t)g.N * g.N;
   const long long NS = (long long)((T + 63) / 64);
   const double gnu = a.par[o.sc + ((UPDATE || a.elbo_cur) ? SC_G_NU : SC_G_NU_STALE)];   // stand-alone ELBO: the stale one (model.py:970)
+  // (lv0_off: some geometric expectation of this layer has underflowed to 0 -- the weight of a report at mirror count 0 is then the
+  // reference's 0 / 0 -> 0 (model.py:685-696), not 1: no level-0 shortcut in this launch)
+  bool gz = false;
   for (int m = tid; m < Mp; m += nthr) {
-    Gth[m] = a.par[o.G_th + (size_t)l * Mp + m];
+    const double gv = a.par[o.G_th + (size_t)l * Mp + m];
+    Gth[m] = gv;
+    if (LV0 || LV0R) gz = gz || (m < g.M && gv == 0.0);
     if (UPDATE) Lth[m] = a.par[o.l_th + (size_t)l * Mp + m];
   }
   for (int q = tid; q < nHc; q += nthr) Hc[q] = 0.0;
@@ -115,7 +122,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   }
   double Ela[K], Gla[K], Lla[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; Lla[k] = a.par[o.l_la + l * K + k]; }
+  for (int k = 0; k < K; ++k) { Ela[k] = a.par[o.E_la + l * K + k]; Gla[k] = a.par[o.G_la + l * K + k]; Lla[k] = a.par[o.l_la + l * K + k]; if (LV0 || LV0R) gz = gz || Gla[k] == 0.0; }
   const double eps = g.eps;
   // fixed point of the deterministic mode: v * 2^sh rounded to nearest through the 1.5 * 2^52 trick (|v| 2^sh < 2^51: the host caps
   // det_sh at 40 and det_shr at 34 -- counts hold 11 bits, ELBO terms 16 -- and keeps DET_SH_A = 30 for sums of rho)
@@ -233,7 +240,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   if (dbt && lane == 0) dbt[4] = wall_clock64();
 #endif
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step finds nothing of its own outstanding (see the wait in `body`)
-  __syncthreads();   // per-reporter tables
+  bool lv0_off = false;
+  if (LV0 || LV0R) lv0_off = __syncthreads_or(gz ? 1 : 0) != 0;   // per-reporter tables (the barrier), and whether one of them holds a zero
+  else __syncthreads();
 #ifdef SL_DEBUG
   if (dbt && lane == 0) dbt[5] = wall_clock64();
 #endif
@@ -416,7 +425,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // otherwise every round can)
   auto compute = [&](auto rct, const StepIn<K>& cur, const size_t row0, const bool act, const unsigned ea_c, const int Rr, const unsigned sy_word) SL_INL {
     const unsigned ymax = sy_word & 0xffffu, nf = a.farl ? sy_word >> 16 : 0x7fffffffu;
-    const unsigned n1 = (LV0 && a.h0s) ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::h0s) from this round on every report of the step has mirror count 0
+    const unsigned n1 = (LV0 && a.h0s && !lv0_off) ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::h0s) from this round on every report of the step has mirror count 0
     constexpr int RCT = decltype(rct)::value;
     constexpr int NP = RCT < 0 ? PFK : RCT;   // rounds held in registers
     const unsigned cls = cur.cls, qt = cur.qt, tie = cur.tie;
@@ -476,10 +485,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         // others read row 0 with x = 0); lanes whose row lies beyond take the table's formula, per entry and only where some
         // lane needs it.  Rounds past the step's last are empty entries.
         constexpr int GB = Batch<K>::value < 4 ? Batch<K>::value : 4;
-        const unsigned n1u = a.lv0r ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::lv0r) from this round on every report of the step has mirror count 0
+        const unsigned n1u = (LV0R && a.lv0r && !lv0_off) ? sy_word >> 16 : 0x7fffffffu;   // (SlArgs::lv0r) from this round on every report of the step has mirror count 0
         double sl0 = 0.0, sx1 = 0.0;
         rounds(RC<GB>{}, [&](const unsigned (&c)[GB], const unsigned j) SL_INL {
-          if (j >= n1u) {   // level 0: w1 = 1, the factor is E log theta_m + E log lambda_k (the row index is m)
+          if (LV0R && j >= n1u) {   // level 0: w1 = 1, the factor is E log theta_m + E log lambda_k (the row index is m)
             double l0[GB];
 #pragma unroll
             for (int u = 0; u < GB; ++u) l0[u] = Lth[SL_YM(c[u])];
@@ -516,7 +525,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             }
           }
         });
-        if (a.lv0r) {
+        if (LV0R && a.lv0r && !lv0_off) {
 #pragma unroll
           for (int k = 0; k < K; ++k) U[k] += fma(Lla[k], sx1, sl0);
         }
