@@ -348,14 +348,14 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     for (int k = 0; k < K; ++k) f[k] = f_entry(g.mut, lt, gt, Lla[k], Gla[k], gnu_f, (int)y);
   };
   // sum_k e^rho_k (G_theta G_lambda_k + G_nu y) + eps, eps alone outside R  (model.py:967-995)
-  auto elbo_inner = [&](unsigned ent, const double (&er)[K]) SL_INL -> double {
+  // (er: the tie's two sums  sum_k e^rho_k G_lambda_k  and  sum_k e^rho_k -- the sum over k of a report is G_theta_m er[0] + G_nu y er[1]:
+  // two multiply-adds per report whatever K, and K - 2 registers fewer across the walk)
+  auto elbo_inner = [&](unsigned ent, const double (&er)[2]) SL_INL -> double {
     const unsigned ym = SL_YM(ent);
     unsigned y = (unsigned)((float)ym * rcp_mp);
     if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
     const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
-    double inner = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) inner += er[k] * (gt * Gla[k] + z2);
+    const double inner = fma(gt, er[0], z2 * er[1]);
     return (SL_INR(ent) ? inner : 0.0) + eps;
   };
   // U += x F[row] over NP entries whose rows are all in LDS: the table reads in batches, back to back
@@ -382,7 +382,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     }
   };
   // H += x rho (+ the ELBO's log terms) over NP entries whose rows are all in LDS; an empty slot adds 0
-  auto walk2_near = [&](const unsigned* e, auto npc, const double (&r)[K], const double (&er)[K]) SL_INL {
+  auto walk2_near = [&](const unsigned* e, auto npc, const double (&r)[K], const double (&er)[2]) SL_INL {
 #ifndef SL_LG
 #define SL_LG 2
 #endif
@@ -457,9 +457,9 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
         }
       }
     };
-    double r[K], er[K];
+    double r[K], er[2] = {0.0, 0.0};   // er: sum_k e^rho_k G_lambda_k, sum_k e^rho_k (elbo_inner)
 #pragma unroll
-    for (int k = 0; k < K; ++k) { r[k] = act ? cur.w[k] : 0.0; er[k] = 0.0; }   // (positions past the last tie read slack rows)
+    for (int k = 0; k < K; ++k) r[k] = act ? cur.w[k] : 0.0;   // (positions past the last tie read slack rows)
     if (a.do_hist == 2) {   // count mode: every tie "is" category 1 with certainty, so slot 1 of H collects sum x
 #pragma unroll
       for (int k = 0; k < K; ++k) r[k] = (k == 1) ? 1.0 : 0.0;
@@ -601,7 +601,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     }
     if (ELBO) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) er[k] = exp_tab(r[k], xt);   // exp(rho), model.py:971
+      for (int k = 0; k < K; ++k) { const double ek = exp_tab(r[k], xt); er[0] = fma(ek, Gla[k], er[0]); er[1] += ek; }   // exp(rho), model.py:971
     }
     // ---- walk 2: H of the (new) rho, the ELBO's log terms
 #ifdef SL_DEBUG
