@@ -134,7 +134,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   auto lds_add = [&](double* p, double v, double scale) SL_INL {   // an LDS cell: a double, or (DET) a 64-bit fixed-point integer
     if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(p), fxm(v, scale)); else atomicAdd(p, v);
   };
-  const float rcp_mp = 1.0f / (float)Mp;
+  // The level y = row / Mp of a table row (< 2^20 rows, Mp <= 8192) by ONE single-precision multiply-add and a conversion: fl((row + 1/2) / Mp)
+  // is off by less than row 2^-23 / Mp < 1 / (2 Mp), the distance of (row + 1/2) / Mp from the next integer (checked for every Mp and
+  // every boundary row on the host).  (A multiply, a conversion and two corrections before: five vector instructions more per report.)
+  const float rcp_mp = 1.0f / (float)Mp, hrcp_mp = 0.5f * rcp_mp;
+  auto row_level = [&](unsigned ym) SL_INL -> unsigned { return (unsigned)__builtin_fmaf((float)ym, rcp_mp, hrcp_mp); };
   const double lp0_0 = log(1.0 + eps), lp0_k = log(eps);   // the log prior of a tie nobody reported on (the values k_init_rho_pos stored)
   double e_lin = 0.0, e_q = 0.0, e_log = 0.0;
   double accF[K], acc0[K];   // sums over this lane's ties: rho over all-ones mask rows; (SlArgs::h0s) rho_k times the tie's counts in level-0 rounds
@@ -332,16 +336,14 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // w2_k(m, y) = z2 / (z1 + z2), z1 = G_theta_m G_lambda_k, z2 = G_nu y (model.py:694-696; 0 at y = 0 and where both vanish)
   const double gnu_cur = a.par[o.sc + SC_G_NU];
   auto w2_at = [&](unsigned ym, int k) SL_INL -> double {
-    unsigned y = (unsigned)((float)ym * rcp_mp);
-    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const unsigned y = row_level(ym);
     const double z2 = gnu_cur * (double)y, den = Gth[ym - y * (unsigned)Mp] * Gla[k] + z2;
     return (y == 0u || den == 0.0) ? 0.0 : z2 / den;
   };
   // the K factors of a (y, m) row that may lie beyond the LDS levels
   // the factors of a row beyond the LDS levels: the formula of the table, from the per-reporter tables (K divides, no memory)
   auto f_far = [&](unsigned ym, double (&f)[K]) SL_INL {
-    unsigned y = (unsigned)((float)ym * rcp_mp);
-    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const unsigned y = row_level(ym);
     const unsigned m = ym - y * (unsigned)Mp;
     const double lt = Lth[m], gt = Gth[m];
 #pragma unroll
@@ -352,8 +354,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
   // two multiply-adds per report whatever K, and K - 2 registers fewer across the walk)
   auto elbo_inner = [&](unsigned ent, const double (&er)[2]) SL_INL -> double {
     const unsigned ym = SL_YM(ent);
-    unsigned y = (unsigned)((float)ym * rcp_mp);
-    if (y * (unsigned)Mp > ym) --y; else if ((y + 1) * (unsigned)Mp <= ym) ++y;
+    const unsigned y = row_level(ym);
     const double z2 = gnu * (double)y, gt = Gth[ym - y * (unsigned)Mp];
     const double inner = fma(gt, er[0], z2 * er[1]);
     return (SL_INR(ent) ? inner : 0.0) + eps;
