@@ -102,17 +102,20 @@ struct SlUnit { SlArgs a; Geo g; int blk0, nblk; };
 #define SL_LIGHT_UPD_K 2
 #endif
 constexpr bool sl_light(int K, bool elbo, bool allfull, bool update) { return !elbo && allfull && (K <= SL_LIGHT_UPD_K || (!update && K <= 4)); }   // fits 128 registers
+#ifndef SL_ELBO3_K   // ... and the largest K whose ELBO variants are
+#define SL_ELBO3_K 2
+#endif
 #ifndef SL_ELBO3   // K = 2 ELBO variants at 3 waves per SIMD (168 registers, ~20 dwords spilled): 0.259 against 0.282 ms per config-3 launch at 2
 #define SL_ELBO3 1
 #endif
 constexpr int sl_tpb_max(int K, bool elbo, bool allfull, bool update = true) {
-  return elbo ? ((SL_ELBO3 && K <= 2) ? 768 : (K <= 4 ? 512 : 256)) : (sl_light(K, elbo, allfull, update) ? 1024 : (K <= 3 ? 768 : (K <= 7 ? 512 : 256)));
+  return elbo ? ((SL_ELBO3 && K <= SL_ELBO3_K) ? 768 : (K <= 4 ? 512 : 256)) : (sl_light(K, elbo, allfull, update) ? 1024 : (K <= 3 ? 768 : (K <= 7 ? 512 : 256)));
 }
 // ... and of the lockstep entry k_sweep_sl_b (its arguments come from memory: a few registers more than the same variant's own launch)
 constexpr int sl_tpb_max_b(int K, bool elbo, bool allfull) { return elbo ? sl_tpb_max(K, true, allfull) : (K <= 2 ? 768 : (K <= 7 ? 512 : 256)); }
-constexpr int sl_wpe_b(int K, bool elbo, bool allfull) { return elbo ? ((SL_ELBO3 && K <= 2) ? 3 : (K <= 4 ? 2 : 1)) : (K <= 2 ? 3 : (K <= 7 ? 2 : 1)); }
+constexpr int sl_wpe_b(int K, bool elbo, bool allfull) { return elbo ? ((SL_ELBO3 && K <= SL_ELBO3_K) ? 3 : (K <= 4 ? 2 : 1)) : (K <= 2 ? 3 : (K <= 7 ? 2 : 1)); }
 constexpr int sl_wpe(int K, bool elbo, bool allfull, bool update = true) {
-  return elbo ? ((SL_ELBO3 && K <= 2) ? 3 : (K <= 4 ? 2 : 1)) : (sl_light(K, elbo, allfull, update) ? 4 : (K <= 3 ? 3 : (K <= 7 ? 2 : 1)));
+  return elbo ? ((SL_ELBO3 && K <= SL_ELBO3_K) ? 3 : (K <= 4 ? 2 : 1)) : (sl_light(K, elbo, allfull, update) ? 4 : (K <= 3 ? 3 : (K <= 7 ? 2 : 1)));
 }
 
 // LDS bytes of one workgroup of the sweep kernel
