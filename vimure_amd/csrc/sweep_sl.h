@@ -81,6 +81,10 @@ struct SlArgs {
   // null: level 0 like every level.  (Masking the level-0 LANES of mixed rounds instead was measured: an LDS instruction costs
   // the same with half its lanes off.)
   double* h0s;
+  // ... and the statistics pass does not even READ those rounds: what it needs of them is the tie's summed count at mirror count 0,
+  // a constant of the data kept by position (4 bytes per tie instead of 4 per report).  Steps with an irregular tie (a rho that does
+  // not sum to 1: its deficits are per reporter) walk every round as before.  null: the rounds are walked for their counts.
+  const unsigned* x0p;
   int lv0r;   // sy's high half holds that round (the handle's lists are ordered for it): the rho update takes a level-0 round's factors
               // as E log theta_m + E log lambda_k -- one table read per report instead of K
   const unsigned* Ez;   // 64 empty entries (the zeroed slack behind E): what the ring of a long step loads past the step's last round

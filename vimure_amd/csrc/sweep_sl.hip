@@ -32,6 +32,7 @@ struct StepIn {          // what is prefetched for one step
   double v[K];           // log prior (UPDATE or ELBO)
   double w[K];           // current rho (not UPDATE)
   unsigned cls, qt, tie;
+  unsigned x0;           // (SlArgs::x0p) the tie's summed counts at mirror count 0
   unsigned e[sl_pf(K)];
 };
 
@@ -214,6 +215,8 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       d.tie = *at_bytes(pl + row0, lane4);   // (partial mask rows are found by tie)
     }
     if (ELBO && Ql) d.qt = *at_bytes(Ql + row0, lane4);
+    d.x0 = 0u;
+    if (LV0 && a.x0p) d.x0 = *at_bytes(a.x0p + (size_t)l * NS * 64 + row0, lane4);
 #pragma unroll
     for (int k = 0; k < K; ++k) { d.v[k] = 0.0; d.w[k] = 0.0; }
     if (UPDATE || ELBO) {
@@ -439,7 +442,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
     // per entry; round 4 -- the general body issued 57 vector instructions per round of a config-5 layer).
     // use(c, j): GB entries of rounds j .. j + GB - 1, in order.
     const unsigned* pe = El + ea_c;
-    auto rounds = [&](auto gbc, auto&& use) SL_INL {
+    auto rounds = [&](auto gbc, auto&& use, const int Rr) SL_INL {   // (Rr: the rounds to walk -- the step's, or fewer: SlArgs::x0p)
       constexpr int GB = decltype(gbc)::value;
       unsigned rg[PFK];   // the ring: PFK loads in flight, starting from the prefetched rounds
 #pragma unroll
@@ -525,7 +528,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
               }
             }
           }
-        });
+        }, Rr);
         if (LV0R && a.lv0r && !lv0_off) {
 #pragma unroll
           for (int k = 0; k < K; ++k) U[k] += fma(Lla[k], sx1, sl0);
@@ -618,7 +621,11 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
       } else {
         // a general step, as in walk 1: the lanes whose row is in the LDS levels add there (the others add 0 to row 0); rows
         // beyond the levels go to global memory, per entry and only where some lane needs it
-        double sx0 = 0.0;   // (SlArgs::h0s) this tie's counts in the rounds of level 0 only
+        // (SlArgs::x0p: the rounds of level 0 only are not even read -- the tie's counts there are a constant of the data -- unless a tie
+        // of the step is irregular: its deficits are per reporter)
+        const bool skip0 = LV0 && a.x0p != nullptr && a.do_hist == 1 && n1 != 0x7fffffffu && !irr;
+        const int Rw = skip0 ? min(Rr, (int)n1) : Rr;
+        double sx0 = skip0 ? (double)cur.x0 : 0.0;   // (SlArgs::h0s) this tie's counts in the rounds of level 0 only
         rounds(RC<1>{}, [&](const unsigned (&c1)[1], const unsigned j) SL_INL {
           const unsigned c = c1[0], ym = SL_YM(c), x = SL_X(c);
           const bool far_round = j < nf && lim2 != 0xffffffffu;   // (wave-uniform) only such rounds can hold a report beyond the LDS levels
@@ -629,8 +636,10 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             if (irr) lds_add(&Hc[ym], dx * dfc, sc_h);
           } else if (a.do_hist) {
             if (!fr) {   // (far lanes add nothing here: zeros added to one common row would serialise them)
+              if (!(skip0 && ym < (unsigned)Mp)) {   // (SlArgs::x0p: a level-0 report of a mixed round is in the tie's constant too)
 #pragma unroll
-              for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
+                for (int k = 1; k < K; ++k) lds_add(&Hc[(unsigned)k * hcm + ym], dx * r[k], sc_h);
+              }
               if (irr) lds_add(&Hc[ym], dx * dfc, sc_h);   // (wave-uniform: some tie of the step does not sum to 1)
             }
             if (far_round && !a.farl && __any(fr)) {   // (rare) rows beyond the LDS levels: global adds.  Their share of nu is taken from the global
@@ -653,7 +662,7 @@ __device__ __forceinline__ void sweep_body(const SlArgs& a, const Geo& g, const 
             }
           }
           if (ELBO) { const double term = (double)x * log_tab(elbo_inner(c, er), lt); if (DET) ie_log += fxm(term, sc_r); else e_log += term; }
-        });
+        }, Rw);
         if (LV0 && a.h0s && a.do_hist == 1 && act) {
 #pragma unroll
           for (int k = 1; k < K; ++k) acc0[k] = fma(r[k], sx0, acc0[k]);

@@ -1760,7 +1760,8 @@ static SlShape sl_shape(const vmr_ctx* h, bool update, bool elbo, bool hist) {
 }
 static SlArgs sl_args(const vmr_ctx* h, const SlShape& sh, int do_hist, int sum_a = 0) {
   return SlArgs{h->E, h->rs, h->ebase, h->perm, h->sy, h->cls_p, h->Qt_p, h->Rb, h->rq, h->Rm, h->rbase, h->rm2, h->rho, h->logpr, h->par, h->slotR,
-                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, (do_hist == 1 && h->g.two_pass && sh.hc >= 1) ? h->h0s : nullptr, (h->h0s && h->g.two_pass && !getenv("VMR_NO_LV0R")) ? 1 : 0, h->E + h->n_slots, 0};   // (level 0 must be among the LDS levels: its deficits go there)
+                h->lutg, h->Hg, h->slotF, h->slotA, 1, do_hist, sh.yt, sh.hc, sum_a, nullptr, nullptr, 0, 0, nullptr, h->lp0 ? 1 : 0, h->g.farl, (do_hist == 1 && h->g.two_pass && sh.hc >= 1) ? h->h0s : nullptr, (do_hist == 1 && h->g.two_pass && sh.hc >= 1 && h->h0s) ? h->x0p : nullptr,
+                (h->h0s && h->g.two_pass && !getenv("VMR_NO_LV0R")) ? 1 : 0, h->E + h->n_slots, 0};   // (level 0 must be among the LDS levels: its deficits go there)
 }
 static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
   sl_launch_fn fn = vmr_sl_launcher(h->g.K);
@@ -1804,19 +1805,32 @@ static int sl_launch(vmr_ctx* h, int mode, const SlShape& sh, SlArgs& a) {
 // per step, a lane walks its tie's column and swaps a far report with the first near one -- so that only the first nf rounds of a
 // step (nf = the most far reports any of its 64 ties has; stored in the high half of sy) ever take the pass' far-level code: left
 // where they fall, 2 % of far reports put one into two rounds of three.
-__global__ __launch_bounds__(256) void k_far_first(unsigned* __restrict__ E, const unsigned* __restrict__ rsl, unsigned* __restrict__ syl, size_t NS, unsigned rows_near) {
+// slots read by a statistics pass that skips the rounds of level 0 only: sum over steps of 64 min(R, n1)  (vmr_kernel_bytes)
+__global__ __launch_bounds__(256) void k_stat_slots(const unsigned* __restrict__ rsl, const unsigned* __restrict__ syl, size_t NS, unsigned long long* __restrict__ out) {
+  unsigned long long v = 0;
+  for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < NS; s += (size_t)gridDim.x * 256) {
+    const unsigned R = (rsl[s + 1] - rsl[s]) >> 6, n1 = syl[s] >> 16;
+    v += 64ull * (unsigned long long)min(R, n1);
+  }
+  if (v) atomicAdd(out, v);
+}
+// x0 != null: also the tie's summed counts of the near reports, by position (SlArgs::x0p).
+__global__ __launch_bounds__(256) void k_far_first(unsigned* __restrict__ E, const unsigned* __restrict__ rsl, unsigned* __restrict__ syl, size_t NS, unsigned rows_near,
+                                                   unsigned* __restrict__ x0) {
   const int lane = threadIdx.x & 63;
   for (size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < NS; s += (size_t)gridDim.x * 4) {
     const unsigned ea = rsl[s], R = (rsl[s + 1] - ea) >> 6;
     unsigned* col = E + (size_t)ea + lane;
     unsigned f = 0;   // far reports found so far = the slot the next one goes to
+    unsigned xs = 0;
     for (unsigned r = 0; r < R; ++r) {
       const unsigned e = col[(size_t)r * 64];
       if (e != 0u && SL_YM(e) >= rows_near) {
         if (f != r) { const unsigned o = col[(size_t)f * 64]; col[(size_t)f * 64] = e; col[(size_t)r * 64] = o; }
         ++f;
-      }
+      } else xs += SL_X(e);
     }
+    if (x0) x0[s * 64 + (unsigned)lane] = xs;
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) f = max(f, (unsigned)__shfl_xor((int)f, o2, 64));
     if (lane == 0) syl[s] = (syl[s] & 0xffffu) | (min(f, 0xffffu) << 16);
@@ -2516,7 +2530,7 @@ static int build_far_lists(vmr_ctx* h) {
   CK(hipMemcpy(eb.data(), h->ebase, (size_t)g.L * 8, hipMemcpyDeviceToHost));
   for (int l = 0; l < g.L; ++l) {
     hipLaunchKernelGGL(k_far_first, dim3((unsigned)std::min<size_t>(8192, (NS + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS + 1),
-                       h->sy + (size_t)l * NS, NS, (unsigned)g.hc * (unsigned)g.Mp);
+                       h->sy + (size_t)l * NS, NS, (unsigned)g.hc * (unsigned)g.Mp, (unsigned*)nullptr);
     CK(hipGetLastError());
     CK(hipMemsetAsync(cnt, 0, 8, h->stream));
     hipLaunchKernelGGL(k_far_collect, dim3((unsigned)std::min<size_t>(8192, (NS + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS + 1), NS,
@@ -2691,10 +2705,22 @@ static int create_tail(vmr_ctx* h, const hipDeviceProp_t& prop) {
       const size_t T_ = (size_t)g.N * g.N, NS_ = (T_ + 63) / 64;
       std::vector<unsigned long long> eb(L);
       CK(hipMemcpy(eb.data(), h->ebase, (size_t)L * 8, hipMemcpyDeviceToHost));
+      if (!getenv("VMR_NO_X0")) CK(hipMalloc(&h->x0p, (size_t)L * NS_ * 64 * 4));
       for (int l = 0; l < L; ++l)
         hipLaunchKernelGGL(k_far_first, dim3((unsigned)std::min<size_t>(8192, (NS_ + 3) / 4)), dim3(256), 0, h->stream, h->E + eb[l], h->rs + (size_t)l * (NS_ + 1),
-                           h->sy + (size_t)l * NS_, NS_, (unsigned)g.Mp);
+                           h->sy + (size_t)l * NS_, NS_, (unsigned)g.Mp, h->x0p ? h->x0p + (size_t)l * NS_ * 64 : nullptr);
       CK(hipGetLastError());
+      if (h->x0p) {
+        unsigned long long* ss = nullptr;
+        CK(hipMalloc(&ss, 8));
+        CK(hipMemsetAsync(ss, 0, 8, h->stream));
+        for (int l = 0; l < L; ++l)
+          hipLaunchKernelGGL(k_stat_slots, dim3(256), dim3(256), 0, h->stream, h->rs + (size_t)l * (NS_ + 1), h->sy + (size_t)l * NS_, NS_, ss);
+        hipError_t es = hipMemcpyAsync(&h->stat_slots, ss, 8, hipMemcpyDeviceToHost, h->stream);
+        if (es == hipSuccess) es = hipStreamSynchronize(h->stream);
+        (void)hipFree(ss);
+        CK(es);
+      }
       const size_t n0 = (size_t)L * NSLOT * K + L;
       CK(hipMalloc(&h->h0s, n0 * 8));
       CK(hipMemsetAsync(h->h0s, 0, n0 * 8, h->stream));
@@ -3215,7 +3241,7 @@ void vmr_destroy(vmr_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.ex);
-  void* ptrs[] = {h->h0s, h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
+  void* ptrs[] = {h->x0p, h->h0s, h->far_pos, h->far_ent, h->far_base, h->EX, h->gen_s1, h->rm2, h->det_buf, h->fr_slots, h->nu_acc, h->fin_g, h->perm, h->sy, h->cls_p, h->Qt_p, h->nat, h->rho_snap, h->par_snap, h->rq, h->Rm, h->rbase, h->E, h->rs, h->Cg, h->Qt, h->ebase, h->rcls, h->X, h->Rb, h->cov, h->sumx, h->rho, h->logpr, h->par, h->slotA, h->slotR, h->elbo_dev, h->lutg, h->Hg, h->xmax, h->slotF, h->npartial};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -4043,7 +4069,9 @@ int vmr_kernel_bytes(vmr_handle h, int kernel_class, double* bytes) {
     const double Q = g.mut ? 4.0 * ties : 0.0;
     switch (kernel_class) {
       case VMR_KERNEL_GAMMA_MASK: *bytes = ties + (h->rq ? 4.0 * ties + 2.0 * (double)h->n_rm : (double)h->n_partial * g.W * 8.0) + Srho; break;
-      case VMR_KERNEL_GAMMA_COUNTS: *bytes = E + RP + Srho; break;
+      case VMR_KERNEL_GAMMA_COUNTS:   // (x0p: the rounds of level 0 only are not read -- a count per tie instead)
+        *bytes = ((h->x0p && g.two_pass) ? 4.0 * (double)h->stat_slots + 4.0 * ties : E) + RP + Srho;
+        break;
       case VMR_KERNEL_RHO: *bytes = E + RP + mask + 2.0 * Srho; break;
       case VMR_KERNEL_RHO_NOSTORE: *bytes = E + RP + mask + Srho; break;   // (the log prior is read, rho is not written)
       case VMR_KERNEL_ELBO: *bytes = E + RP + mask + Q + 2.0 * Srho; break;

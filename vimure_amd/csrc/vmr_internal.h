@@ -113,6 +113,8 @@ struct vmr_ctx {
   std::vector<unsigned long long> far_off;
   double* h0s = nullptr;       // level-0 rounds without LDS adds (SlArgs::h0s): [L][NSLOT][K] sums over ties of rho_k times the tie's counts in
                                // such rounds, then [L] sum_m C[l][0][m]
+  unsigned long long stat_slots = 0;   // ... the entry slots its statistics pass still reads (the rounds before a step's first all-level-0 one)
+  unsigned* x0p = nullptr;     // ... and [L][NS * 64], by position: a tie's summed counts at mirror count 0 (SlArgs::x0p)
   bool elbo_split = false;     // Geo::farl: the fused rho + ELBO variant does not keep g.hc levels in LDS (its logarithm table): an ELBO sweep is
                                // the plain update pass followed by the ELBO-only pass (same numbers: the stale G_nu, model.py:970)
   uint8_t* cls_p = nullptr;    // [L][T] rcls by position (null when every row is all ones)
