@@ -218,7 +218,7 @@ def test_two_passes_level_zero_rounds_with_and_without_mask(mask, monkeypatch):
     """The statistics pass of a two-pass handle with long lists: ties sorted by (reports, reports of mirror count >= 1), the
     level-0 rounds of a step add nothing to the LDS table (their marginals go through per-tie products, SlArgs::h0s) and the rho
     pass takes their factors from the per-reporter table -- K = 3, 640 reporters, two passes forced on a small network, all-ones
-    and partial mask rows, against the coordinate-list oracle; VMR_NO_LEVEL0 / VMR_NO_LEVEL_SORT give the same numbers."""
+    and partial mask rows, against the coordinate-list oracle; VMR_NO_LEVEL0 / VMR_NO_LEVEL_SORT / VMR_NO_X0 give the same numbers."""
     from oracle import cavi_coo
     from vimure_amd import CaviEngine
     monkeypatch.setenv("VMR_FORMAT", "sparse")
@@ -230,12 +230,15 @@ def test_two_passes_level_zero_rounds_with_and_without_mask(mask, monkeypatch):
     R = None if mask == "ones" else (g.rand(L, N, N, M) < 0.7).astype(np.uint8)
     sx = np.nonzero(X)
     elbos = {}
-    for variant in ("default", "no_level0", "no_level_sort"):
+    for variant in ("default", "no_level0", "no_level_sort", "no_x0"):
         if variant == "no_level0":
             monkeypatch.setenv("VMR_NO_LEVEL0", "1")
         elif variant == "no_level_sort":
             monkeypatch.delenv("VMR_NO_LEVEL0")
             monkeypatch.setenv("VMR_NO_LEVEL_SORT", "1")
+        elif variant == "no_x0":   # (the level-0 rounds are walked for their counts instead of taken from the per-tie constant)
+            monkeypatch.delenv("VMR_NO_LEVEL_SORT")
+            monkeypatch.setenv("VMR_NO_X0", "1")
         eng = CaviEngine(X, R, K=K, mutuality=True, device=0)
         assert eng.data_format()[0] == "sparse" and eng.sweep_shape()[0] == 2
         sum_x, cov = eng.data_stats()
